@@ -1,0 +1,61 @@
+// Internal declarations shared by the translation units of libscp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "scp_hip.h"
+
+struct scp_ctx {
+  int device;
+  hipStream_t stream;
+  char err[512];
+  // small device scratch for reductions / host read-back
+  double* d_scratch;      // 64 doubles
+  double* h_scratch;      // pinned, 64 doubles
+  hipEvent_t ev0, ev1;
+  double* tm_scratch;     // time-major copy of a trajectory array for the pairwise passes (grown on demand)
+  size_t tm_bytes;
+};
+
+static inline int scp_fail(scp_ctx* ctx, int code, const char* fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define SCP_HIP_CHECK(ctx, call)                                                                     \
+  do {                                                                                               \
+    hipError_t e_ = (call);                                                                          \
+    if (e_ != hipSuccess)                                                                            \
+      return scp_fail((ctx), SCP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),    \
+                      __FILE__, __LINE__);                                                           \
+  } while (0)
+
+#define SCP_REQUIRE(ctx, cond, ...)                                   \
+  do {                                                                \
+    if (!(cond)) return scp_fail((ctx), SCP_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+static inline int64_t scp_pairs(int N) { return (int64_t)N * (N - 1) / 2; }
+static inline int scp_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- internal launchers (time-major device layout [K][C], C = N*D) --------------------------------
+// Y[R][C] = alpha * A[R][M] X[M][C] + beta * Y   (row-major; A small and L2 resident)
+int scp_launch_gemm(scp_ctx* ctx, int use_mfma, int R, int M, int C, double alpha, const double* A,
+                    const double* X, double beta, double* Y);
+// [N][K][D] <-> [K][N*D]
+int scp_launch_to_time_major(scp_ctx* ctx, int N, int K, int D, const double* src, double* dst);
+int scp_launch_from_time_major(scp_ctx* ctx, int N, int K, int D, const double* src, double* dst);
+// fixed-row bounds in time-major stacked layout: rows [0,K-1) jerk, [K-1,2K-1) acc, [2K-1,3K-1) vel,
+// [3K-1,4K-1) pos, each row C = N*D wide.
+int scp_launch_bounds_time_major(scp_ctx* ctx, int N, int K, int D, double h, const double* limits_host,
+                                 const double* space_host, const double* p0, const double* v0,
+                                 const double* pf, const double* vf, double* l_tm, double* u_tm);

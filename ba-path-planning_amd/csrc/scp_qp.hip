@@ -1,0 +1,831 @@
+// Joint QP of the SCP iteration on gfx950 (rows a3 / a6 / a9 of SURVEY.md section 8).
+//
+//   min ||x||^2   s.t.   l_f <= F x <= u_f  (jerk, acc, vel, pos rows; scp.py:182-257, :332-358)
+//                        A_W x >= l_W       (working set of collision rows; scp.py:453-557)
+//
+// replaces osqp.OSQP().setup/warm_start/solve (scp.py:326-367, :441-449).  The algorithm is OSQP's ADMM
+// (rho / sigma / alpha, rho x 1e3 on equality rows, adaptive rho, termination test every 25 iterations on the
+// unscaled inf-norm residuals) with an indirect x-update, as OSQP's own GPU backend does:
+//
+//   ((2 + sigma) I + F^T R_f F + A_W^T R_c A_W) x~ = sigma x + F^T (R_f z_f - y_f) + A_W^T (R_c z_c - y_c)
+//
+// is solved by PCG.  The fixed part H_f = (2+sigma) I + F^T R_f F is the same K x K block for EVERY
+// (agent, axis) column, so its exact inverse (one small dense factorisation per rho) is the
+// preconditioner and is applied to all N*D columns at once as a [K x K] x [K x N*D] product on the fp64 MFMA
+// units; A_W is never formed: row (k, i, j) is  eta . ((S0 x_i)[k] - (S0 x_j)[k]).
+//
+// Device layout: every vector lives time-major, [rows][C] with C = N*D columns (c = i*D + d).  Fixed rows are
+// stacked as  [0,K-1) jerk | [K-1,2K-1) acc | [2K-1,3K-1) vel | [3K-1,4K-1) pos.
+// oracle/qp_oracle.py:admm_structured is the line-by-line CPU statement of this file.
+#include "scp_common.h"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr int NPART = 128;  // partial sums of a dot product (fixed -> deterministic summation order)
+
+enum Slot {  // device scalar slots (doubles)
+  SL_RZ0 = 0, SL_RZ1 = 1,
+  SL_RP = 8, SL_NAX = 9, SL_NZ = 10, SL_RD = 11, SL_NPX = 12, SL_NATY = 13,
+  SL_COUNT = 32
+};
+
+struct QpDev {
+  // constant blocks
+  double *F, *Ft, *S0, *S0t, *HS, *Hf, *Minv, *aug, *wrow;
+  // fixed rows
+  double *lf, *uf, *zf, *yf, *wf, *tf;
+  // x-space vectors [K][C]
+  double *x, *xt, *rhs, *r, *p, *zz, *G;
+  double* HQ;  // [2K][C]: rows [0,K) = H v, rows [K,2K) = S0 v
+  // working rows
+  int64_t* w_row;
+  int *w_k, *w_i, *w_j;
+  double *w_eta, *w_l, *zc, *yc;
+  // scalars
+  double* scal;   // SL_COUNT
+  double* part;   // 2 * NPART
+};
+
+}  // namespace
+
+struct scp_qp {
+  scp_ctx* ctx;
+  int N, K, D, Rf;
+  int64_t C;
+  double h;
+  scp_qp_settings st;
+  int64_t row_cap, nW;
+  bool problem_set, reset_done;
+  double rho;
+  QpDev d;
+  double* h_scal;  // pinned
+};
+
+// ----------------------------------------------------------------------------------------------------
+// kernels
+// ----------------------------------------------------------------------------------------------------
+__device__ inline double sum_partials(const double* part) {
+  double s = 0.0;
+  for (int b = 0; b < NPART; ++b) s += part[b];
+  return s;
+}
+
+// part[b] = sum over this block's grid-stride share of a.b (fixed tree, deterministic)
+__global__ __launch_bounds__(256) void dot_partial_kernel(int64_t n, const double* __restrict__ a,
+                                                           const double* __restrict__ b, double* __restrict__ part) {
+  __shared__ double s[4];
+  double acc = 0.0;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)NPART * 256) acc += a[t] * b[t];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+// wf = rho * w[row] * zf - yf   (Rf x C);  rhs = sigma * x  (K x C, first K*C threads)
+__global__ __launch_bounds__(256) void admm_rhs_prep_kernel(int64_t nf, int64_t nx, int64_t C, double rho, double sigma,
+                                                             const double* __restrict__ wrow,
+                                                             const double* __restrict__ zf,
+                                                             const double* __restrict__ yf, double* __restrict__ wf,
+                                                             const double* __restrict__ x, double* __restrict__ rhs) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < nf) wf[t] = rho * wrow[t / C] * zf[t] - yf[t];
+  if (t < nx) rhs[t] = sigma * x[t];
+}
+
+enum RowMode { ROW_RHS = 0, ROW_HMUL = 1, ROW_Y = 2 };
+
+// G[k][i] += eta g, G[k][j] -= eta g  for every working row; g depends on the mode:
+//   ROW_RHS : rho zc - yc            (right-hand side of the x-update)
+//   ROW_HMUL: rho eta.(Q_i - Q_j)    (A_W^T R_c A_W v, Q = S0 v)
+//   ROW_Y   : yc                     (A_W^T y for the dual residual)
+template <int D, int MODE>
+__global__ __launch_bounds__(256) void row_scatter_kernel(int64_t nW, int64_t C, double rho,
+                                                           const int* __restrict__ wk, const int* __restrict__ wi,
+                                                           const int* __restrict__ wj,
+                                                           const double* __restrict__ weta,
+                                                           const double* __restrict__ zc,
+                                                           const double* __restrict__ yc,
+                                                           const double* __restrict__ Q, double* __restrict__ G) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= nW) return;
+  const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
+  const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
+  double e[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) e[d] = weta[n * D + d];
+  double g;
+  if (MODE == ROW_RHS) {
+    g = rho * zc[n] - yc[n];
+  } else if (MODE == ROW_HMUL) {
+    double ax = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) ax += e[d] * (Q[bi + d] - Q[bj + d]);
+    g = rho * ax;
+  } else {
+    g = yc[n];
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const double c = e[d] * g;
+    atomicAdd(G + bi + d, c);
+    atomicAdd(G + bj + d, -c);
+  }
+}
+
+// r = rhs - Hx
+__global__ __launch_bounds__(256) void cg_residual_kernel(int64_t n, const double* __restrict__ rhs,
+                                                           const double* __restrict__ Hx, double* __restrict__ r) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < n) r[t] = rhs[t] - Hx[t];
+}
+
+// p = zz ; scal[SL_RZ0] = sum(part)
+__global__ __launch_bounds__(256) void cg_start_kernel(int64_t n, const double* __restrict__ zz, double* __restrict__ p,
+                                                        const double* __restrict__ part, double* __restrict__ scal) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < n) p[t] = zz[t];
+  if (t == 0) scal[SL_RZ0] = sum_partials(part);
+}
+
+// alpha = rz / pHp ; xt += alpha p ; r -= alpha Hp
+__global__ __launch_bounds__(256) void cg_update_kernel(int64_t n, int slot, const double* __restrict__ scal,
+                                                         const double* __restrict__ part_pHp,
+                                                         const double* __restrict__ p, const double* __restrict__ Hp,
+                                                         double* __restrict__ xt, double* __restrict__ r) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const double rz = scal[slot];
+  const double pHp = sum_partials(part_pHp);
+  const double alpha = (pHp > 0.0 && rz != 0.0) ? rz / pHp : 0.0;
+  if (t < n) {
+    xt[t] += alpha * p[t];
+    r[t] -= alpha * Hp[t];
+  }
+}
+
+// beta = rz_new / rz ; p = zz + beta p ; scal[slot^1] = rz_new
+__global__ __launch_bounds__(256) void cg_direction_kernel(int64_t n, int slot, double* __restrict__ scal,
+                                                            const double* __restrict__ part_rz,
+                                                            const double* __restrict__ zz, double* __restrict__ p) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const double rz = scal[slot];
+  const double rz_new = sum_partials(part_rz);
+  const double beta = rz != 0.0 ? rz_new / rz : 0.0;
+  if (t < n) p[t] = zz[t] + beta * p[t];
+  if (t == 0) scal[slot ^ 1] = rz_new;
+}
+
+// fixed rows: relaxation, projection, dual update (OSQP steps 4-6);  x = alpha xt + (1-alpha) x
+__global__ __launch_bounds__(256) void admm_fixed_update_kernel(int64_t nf, int64_t nx, int64_t C, double rho,
+                                                                 double alpha, const double* __restrict__ wrow,
+                                                                 const double* __restrict__ tf,
+                                                                 const double* __restrict__ lf,
+                                                                 const double* __restrict__ uf, double* __restrict__ zf,
+                                                                 double* __restrict__ yf, const double* __restrict__ xt,
+                                                                 double* __restrict__ x) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < nf) {
+    const double rr = rho * wrow[t / C];
+    const double zh = alpha * tf[t] + (1.0 - alpha) * zf[t];
+    const double y = yf[t];
+    const double zn = fmin(fmax(zh + y / rr, lf[t]), uf[t]);
+    yf[t] = y + rr * (zh - zn);
+    zf[t] = zn;
+  }
+  if (t < nx) x[t] = alpha * xt[t] + (1.0 - alpha) * x[t];
+}
+
+// collision rows: same update with u = +inf
+template <int D>
+__global__ __launch_bounds__(256) void admm_row_update_kernel(int64_t nW, int64_t C, double rho, double alpha,
+                                                               const int* __restrict__ wk, const int* __restrict__ wi,
+                                                               const int* __restrict__ wj,
+                                                               const double* __restrict__ weta,
+                                                               const double* __restrict__ wl,
+                                                               const double* __restrict__ Q, double* __restrict__ zc,
+                                                               double* __restrict__ yc) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= nW) return;
+  const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
+  const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
+  double tc = 0.0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) tc += weta[n * D + d] * (Q[bi + d] - Q[bj + d]);
+  const double zh = alpha * tc + (1.0 - alpha) * zc[n];
+  const double y = yc[n];
+  const double zn = fmax(zh + y / rho, wl[n]);
+  yc[n] = y + rho * (zh - zn);
+  zc[n] = zn;
+}
+
+__device__ inline void atomic_max_nonneg(double* addr, double v) {
+  atomicMax((unsigned long long*)addr, (unsigned long long)__double_as_longlong(v));
+}
+
+__device__ inline double block_max(double v) {
+  __shared__ double s[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double m = fmax(fmax(s[0], s[1]), fmax(s[2], s[3]));
+  __syncthreads();
+  return m;
+}
+
+// primal residual pieces over the fixed rows: max|Fx - z|, max|Fx|, max|z|
+__global__ __launch_bounds__(256) void resid_fixed_kernel(int64_t nf, const double* __restrict__ tf,
+                                                           const double* __restrict__ zf, double* __restrict__ scal) {
+  double rp = 0.0, na = 0.0, nz = 0.0;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nf; t += (int64_t)gridDim.x * 256) {
+    const double a = tf[t], z = zf[t];
+    rp = fmax(rp, fabs(a - z));
+    na = fmax(na, fabs(a));
+    nz = fmax(nz, fabs(z));
+  }
+  rp = block_max(rp);
+  na = block_max(na);
+  nz = block_max(nz);
+  if (threadIdx.x == 0) {
+    atomic_max_nonneg(scal + SL_RP, rp);
+    atomic_max_nonneg(scal + SL_NAX, na);
+    atomic_max_nonneg(scal + SL_NZ, nz);
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void resid_rows_kernel(int64_t nW, int64_t C, const int* __restrict__ wk,
+                                                          const int* __restrict__ wi, const int* __restrict__ wj,
+                                                          const double* __restrict__ weta,
+                                                          const double* __restrict__ Q, const double* __restrict__ zc,
+                                                          double* __restrict__ scal) {
+  double rp = 0.0, na = 0.0, nz = 0.0;
+  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nW; n += (int64_t)gridDim.x * 256) {
+    const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
+    const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
+    double a = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) a += weta[n * D + d] * (Q[bi + d] - Q[bj + d]);
+    const double z = zc[n];
+    rp = fmax(rp, fabs(a - z));
+    na = fmax(na, fabs(a));
+    nz = fmax(nz, fabs(z));
+  }
+  rp = block_max(rp);
+  na = block_max(na);
+  nz = block_max(nz);
+  if (threadIdx.x == 0) {
+    atomic_max_nonneg(scal + SL_RP, rp);
+    atomic_max_nonneg(scal + SL_NAX, na);
+    atomic_max_nonneg(scal + SL_NZ, nz);
+  }
+}
+
+// dual residual pieces: max|2x + ATy|, max|2x|, max|ATy|
+__global__ __launch_bounds__(256) void resid_dual_kernel(int64_t nx, const double* __restrict__ x,
+                                                          const double* __restrict__ aty, double* __restrict__ scal) {
+  double rd = 0.0, npx = 0.0, nat = 0.0;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nx; t += (int64_t)gridDim.x * 256) {
+    const double px = 2.0 * x[t], a = aty[t];
+    rd = fmax(rd, fabs(px + a));
+    npx = fmax(npx, fabs(px));
+    nat = fmax(nat, fabs(a));
+  }
+  rd = block_max(rd);
+  npx = block_max(npx);
+  nat = block_max(nat);
+  if (threadIdx.x == 0) {
+    atomic_max_nonneg(scal + SL_RD, rd);
+    atomic_max_nonneg(scal + SL_NPX, npx);
+    atomic_max_nonneg(scal + SL_NATY, nat);
+  }
+}
+
+// Hf[a][b] = (2 + sigma) delta_ab + rho * sum_r w_r F[r][a] F[r][b];  HS = [Hf ; S0]
+__global__ __launch_bounds__(256) void build_hf_kernel(int K, int Rf, double rho, double sigma,
+                                                        const double* __restrict__ F, const double* __restrict__ wrow,
+                                                        const double* __restrict__ S0, double* __restrict__ Hf,
+                                                        double* __restrict__ HS, double* __restrict__ aug) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= K * K) return;
+  const int a = t / K, b = t % K;
+  double s = 0.0;
+  for (int r = 0; r < Rf; ++r) s += wrow[r] * F[(int64_t)r * K + a] * F[(int64_t)r * K + b];
+  const double v = rho * s + (a == b ? 2.0 + sigma : 0.0);
+  Hf[t] = v;
+  HS[t] = v;
+  HS[K * K + t] = S0[t];
+  aug[(int64_t)a * 2 * K + b] = v;
+  aug[(int64_t)a * 2 * K + K + b] = a == b ? 1.0 : 0.0;
+}
+
+// Gauss-Jordan inverse of the SPD matrix held in aug = [Hf | I] (K x 2K, global memory, one workgroup).
+__global__ __launch_bounds__(1024) void spd_inverse_kernel(int K, double* __restrict__ aug, double* __restrict__ Minv) {
+  extern __shared__ double sh[];  // prow[2K] | col[K]
+  double* prow = sh;
+  double* col = sh + 2 * K;
+  const int W = 2 * K;
+  for (int p = 0; p < K; ++p) {
+    const double piv = aug[(int64_t)p * W + p];
+    for (int c = threadIdx.x; c < W; c += blockDim.x) prow[c] = aug[(int64_t)p * W + c] / piv;
+    for (int r = threadIdx.x; r < K; r += blockDim.x) col[r] = aug[(int64_t)r * W + p];
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * W; e += blockDim.x) {
+      const int r = e / W, c = e % W;
+      if (r == p) aug[e] = prow[c];
+      else aug[e] -= col[r] * prow[c];
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < K * K; e += blockDim.x) Minv[e] = aug[(int64_t)(e / K) * W + K + (e % K)];
+}
+
+// append working rows: decode (k, i, j), copy eta / l, z = max(A x, l), y = 0
+__global__ __launch_bounds__(256) void add_rows_kernel(int N, int D, int64_t C, int64_t pairs, int64_t base, int64_t n,
+                                                        const int64_t* __restrict__ rows,
+                                                        const double* __restrict__ eta_in,
+                                                        const double* __restrict__ l_in, const double* __restrict__ Q,
+                                                        int64_t* __restrict__ w_row, int* __restrict__ wk,
+                                                        int* __restrict__ wi, int* __restrict__ wj,
+                                                        double* __restrict__ weta, double* __restrict__ wl,
+                                                        double* __restrict__ zc, double* __restrict__ yc) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const int64_t r = rows[t];
+  const int64_t k = r / pairs, q = r % pairs;
+  // lexicographic pair index -> (i, j)
+  const double b = 2.0 * N - 1.0;
+  int64_t ii = (int64_t)((b - sqrt(b * b - 8.0 * (double)q)) * 0.5);
+  if (ii < 0) ii = 0;
+  if (ii > N - 2) ii = N - 2;
+  while (ii * (2LL * N - ii - 1) / 2 > q) --ii;
+  while (ii < N - 2 && (ii + 1) * (2LL * N - ii - 2) / 2 <= q) ++ii;
+  const int64_t jj = q - ii * (2LL * N - ii - 1) / 2 + ii + 1;
+  const int64_t o = base + t;
+  w_row[o] = r;
+  wk[o] = (int)k;
+  wi[o] = (int)ii;
+  wj[o] = (int)jj;
+  double ax = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const double e = eta_in[t * D + d];
+    weta[o * D + d] = e;
+    ax += e * (Q[k * C + ii * D + d] - Q[k * C + jj * D + d]);
+  }
+  const double lo = l_in[t];
+  wl[o] = lo;
+  zc[o] = fmax(ax, lo);
+  yc[o] = 0.0;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------------------
+namespace {
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Carver {
+  char* base;
+  size_t off;
+  template <typename T>
+  T* take(size_t count) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += align_up(count * sizeof(T));
+    return p;
+  }
+};
+
+size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
+  const int Rf = 4 * K - 1;
+  Carver c{static_cast<char*>(ws), 0};
+  d.F = c.take<double>((size_t)Rf * K);
+  d.Ft = c.take<double>((size_t)Rf * K);
+  d.S0 = c.take<double>((size_t)K * K);
+  d.S0t = c.take<double>((size_t)K * K);
+  d.HS = c.take<double>((size_t)2 * K * K);
+  d.Hf = c.take<double>((size_t)K * K);
+  d.Minv = c.take<double>((size_t)K * K);
+  d.aug = c.take<double>((size_t)2 * K * K);
+  d.wrow = c.take<double>((size_t)Rf);
+  const size_t nf = (size_t)Rf * C, nx = (size_t)K * C;
+  d.lf = c.take<double>(nf);
+  d.uf = c.take<double>(nf);
+  d.zf = c.take<double>(nf);
+  d.yf = c.take<double>(nf);
+  d.wf = c.take<double>(nf);
+  d.tf = c.take<double>(nf);
+  d.x = c.take<double>(nx);
+  d.xt = c.take<double>(nx);
+  d.rhs = c.take<double>(nx);
+  d.r = c.take<double>(nx);
+  d.p = c.take<double>(nx);
+  d.zz = c.take<double>(nx);
+  d.G = c.take<double>(nx);
+  d.HQ = c.take<double>(2 * nx);
+  d.w_row = c.take<int64_t>((size_t)cap);
+  d.w_k = c.take<int>((size_t)cap);
+  d.w_i = c.take<int>((size_t)cap);
+  d.w_j = c.take<int>((size_t)cap);
+  d.w_eta = c.take<double>((size_t)cap * D);
+  d.w_l = c.take<double>((size_t)cap);
+  d.zc = c.take<double>((size_t)cap);
+  d.yc = c.take<double>((size_t)cap);
+  d.scal = c.take<double>(SL_COUNT);
+  d.part = c.take<double>(2 * NPART);
+  return c.off;
+}
+
+inline dim3 grid1(int64_t n) { return dim3(scp_cdiv(n, 256)); }
+
+#define QP_CHECK(call)            \
+  do {                            \
+    int rc_ = (call);             \
+    if (rc_ != SCP_OK) return rc_; \
+  } while (0)
+
+#define QP_LAUNCHED(qp) SCP_HIP_CHECK((qp)->ctx, hipGetLastError())
+
+int gemm(scp_qp* qp, int R, int M, double alpha, const double* A, const double* X, double beta, double* Y) {
+  return scp_launch_gemm(qp->ctx, qp->st.use_mfma, R, M, (int)qp->C, alpha, A, X, beta, Y);
+}
+
+template <int MODE>
+int row_scatter(scp_qp* qp, const double* Q) {
+  const QpDev& d = qp->d;
+  hipStream_t s = qp->ctx->stream;
+  SCP_HIP_CHECK(qp->ctx, hipMemsetAsync(d.G, 0, (size_t)qp->K * qp->C * sizeof(double), s));
+  if (qp->D == 2)
+    hipLaunchKernelGGL((row_scatter_kernel<2, MODE>), grid1(qp->nW), dim3(256), 0, s, qp->nW, qp->C, qp->rho, d.w_k,
+                       d.w_i, d.w_j, d.w_eta, d.zc, d.yc, Q, d.G);
+  else
+    hipLaunchKernelGGL((row_scatter_kernel<3, MODE>), grid1(qp->nW), dim3(256), 0, s, qp->nW, qp->C, qp->rho, d.w_k,
+                       d.w_i, d.w_j, d.w_eta, d.zc, d.yc, Q, d.G);
+  QP_LAUNCHED(qp);
+  return SCP_OK;
+}
+
+// HQ[0:K] = H v = Hf v + A_W^T R_c A_W v ; HQ[K:2K] = S0 v
+int hmul(scp_qp* qp, const double* v) {
+  const QpDev& d = qp->d;
+  const int K = qp->K;
+  QP_CHECK(gemm(qp, 2 * K, K, 1.0, d.HS, v, 0.0, d.HQ));
+  if (qp->nW > 0) {
+    QP_CHECK(row_scatter<ROW_HMUL>(qp, d.HQ + (size_t)K * qp->C));
+    QP_CHECK(gemm(qp, K, K, 1.0, d.S0t, d.G, 1.0, d.HQ));
+  }
+  return SCP_OK;
+}
+
+int dot_partial(scp_qp* qp, const double* a, const double* b, double* part) {
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(NPART), dim3(256), 0, qp->ctx->stream, (int64_t)qp->K * qp->C, a, b,
+                     part);
+  QP_LAUNCHED(qp);
+  return SCP_OK;
+}
+
+int build_kkt(scp_qp* qp) {
+  const QpDev& d = qp->d;
+  const int K = qp->K;
+  hipStream_t s = qp->ctx->stream;
+  hipLaunchKernelGGL(build_hf_kernel, grid1((int64_t)K * K), dim3(256), 0, s, K, qp->Rf, qp->rho, qp->st.sigma, d.F,
+                     d.wrow, d.S0, d.Hf, d.HS, d.aug);
+  QP_LAUNCHED(qp);
+  hipLaunchKernelGGL(spd_inverse_kernel, dim3(1), dim3(1024), (size_t)3 * K * sizeof(double), s, K, d.aug, d.Minv);
+  QP_LAUNCHED(qp);
+  return SCP_OK;
+}
+
+int admm_iteration(scp_qp* qp, int* cg_count) {
+  const QpDev& d = qp->d;
+  scp_ctx* ctx = qp->ctx;
+  hipStream_t s = ctx->stream;
+  const int K = qp->K, Rf = qp->Rf;
+  const int64_t C = qp->C, nf = (int64_t)Rf * C, nx = (int64_t)K * C;
+  // rhs = sigma x + F^T (R_f z_f - y_f) + A_W^T (R_c z_c - y_c)
+  hipLaunchKernelGGL(admm_rhs_prep_kernel, grid1(nf), dim3(256), 0, s, nf, nx, C, qp->rho, qp->st.sigma, d.wrow, d.zf,
+                     d.yf, d.wf, d.x, d.rhs);
+  QP_LAUNCHED(qp);
+  QP_CHECK(gemm(qp, K, Rf, 1.0, d.Ft, d.wf, 1.0, d.rhs));
+  if (qp->nW > 0) {
+    QP_CHECK(row_scatter<ROW_RHS>(qp, nullptr));
+    QP_CHECK(gemm(qp, K, K, 1.0, d.S0t, d.G, 1.0, d.rhs));
+    // PCG on H x~ = rhs, preconditioner Minv, warm start x~ = x
+    SCP_HIP_CHECK(ctx, hipMemcpyAsync(d.xt, d.x, nx * sizeof(double), hipMemcpyDeviceToDevice, s));
+    QP_CHECK(hmul(qp, d.xt));
+    hipLaunchKernelGGL(cg_residual_kernel, grid1(nx), dim3(256), 0, s, nx, d.rhs, d.HQ, d.r);
+    QP_LAUNCHED(qp);
+    QP_CHECK(gemm(qp, K, K, 1.0, d.Minv, d.r, 0.0, d.zz));
+    QP_CHECK(dot_partial(qp, d.r, d.zz, d.part));
+    hipLaunchKernelGGL(cg_start_kernel, grid1(nx), dim3(256), 0, s, nx, d.zz, d.p, d.part, d.scal);
+    QP_LAUNCHED(qp);
+    int slot = SL_RZ0;
+    for (int it = 0; it < qp->st.cg_iters; ++it) {
+      QP_CHECK(hmul(qp, d.p));
+      QP_CHECK(dot_partial(qp, d.p, d.HQ, d.part));
+      hipLaunchKernelGGL(cg_update_kernel, grid1(nx), dim3(256), 0, s, nx, slot, d.scal, d.part, d.p, d.HQ, d.xt, d.r);
+      QP_LAUNCHED(qp);
+      QP_CHECK(gemm(qp, K, K, 1.0, d.Minv, d.r, 0.0, d.zz));
+      QP_CHECK(dot_partial(qp, d.r, d.zz, d.part + NPART));
+      hipLaunchKernelGGL(cg_direction_kernel, grid1(nx), dim3(256), 0, s, nx, slot, d.scal, d.part + NPART, d.zz, d.p);
+      QP_LAUNCHED(qp);
+      slot ^= 1;
+      ++*cg_count;
+    }
+  } else {
+    QP_CHECK(gemm(qp, K, K, 1.0, d.Minv, d.rhs, 0.0, d.xt));
+  }
+  // z~ = A x~, relaxation, projection, duals
+  QP_CHECK(gemm(qp, Rf, K, 1.0, d.F, d.xt, 0.0, d.tf));
+  if (qp->nW > 0) {
+    QP_CHECK(gemm(qp, K, K, 1.0, d.S0, d.xt, 0.0, d.HQ + nx));
+    if (qp->D == 2)
+      hipLaunchKernelGGL(admm_row_update_kernel<2>, grid1(qp->nW), dim3(256), 0, s, qp->nW, C, qp->rho, qp->st.alpha,
+                         d.w_k, d.w_i, d.w_j, d.w_eta, d.w_l, d.HQ + nx, d.zc, d.yc);
+    else
+      hipLaunchKernelGGL(admm_row_update_kernel<3>, grid1(qp->nW), dim3(256), 0, s, qp->nW, C, qp->rho, qp->st.alpha,
+                         d.w_k, d.w_i, d.w_j, d.w_eta, d.w_l, d.HQ + nx, d.zc, d.yc);
+    QP_LAUNCHED(qp);
+  }
+  hipLaunchKernelGGL(admm_fixed_update_kernel, grid1(nf), dim3(256), 0, s, nf, nx, C, qp->rho, qp->st.alpha, d.wrow,
+                     d.tf, d.lf, d.uf, d.zf, d.yf, d.xt, d.x);
+  QP_LAUNCHED(qp);
+  return SCP_OK;
+}
+
+// residuals -> qp->h_scal[SL_RP..SL_NATY] (synchronises the stream)
+int residuals(scp_qp* qp) {
+  const QpDev& d = qp->d;
+  scp_ctx* ctx = qp->ctx;
+  hipStream_t s = ctx->stream;
+  const int K = qp->K, Rf = qp->Rf;
+  const int64_t C = qp->C, nf = (int64_t)Rf * C, nx = (int64_t)K * C;
+  SCP_HIP_CHECK(ctx, hipMemsetAsync(d.scal + SL_RP, 0, 6 * sizeof(double), s));
+  QP_CHECK(gemm(qp, Rf, K, 1.0, d.F, d.x, 0.0, d.tf));
+  hipLaunchKernelGGL(resid_fixed_kernel, dim3(256), dim3(256), 0, s, nf, d.tf, d.zf, d.scal);
+  QP_LAUNCHED(qp);
+  // ATy -> rhs (scratch)
+  QP_CHECK(gemm(qp, K, Rf, 1.0, d.Ft, d.yf, 0.0, d.rhs));
+  if (qp->nW > 0) {
+    QP_CHECK(gemm(qp, K, K, 1.0, d.S0, d.x, 0.0, d.HQ + nx));
+    const int blocks = (int)((qp->nW + 255) / 256) < 256 ? (int)((qp->nW + 255) / 256) : 256;
+    if (qp->D == 2)
+      hipLaunchKernelGGL(resid_rows_kernel<2>, dim3(blocks), dim3(256), 0, s, qp->nW, C, d.w_k, d.w_i, d.w_j, d.w_eta,
+                         d.HQ + nx, d.zc, d.scal);
+    else
+      hipLaunchKernelGGL(resid_rows_kernel<3>, dim3(blocks), dim3(256), 0, s, qp->nW, C, d.w_k, d.w_i, d.w_j, d.w_eta,
+                         d.HQ + nx, d.zc, d.scal);
+    QP_LAUNCHED(qp);
+    QP_CHECK(row_scatter<ROW_Y>(qp, nullptr));
+    QP_CHECK(gemm(qp, K, K, 1.0, d.S0t, d.G, 1.0, d.rhs));
+  }
+  hipLaunchKernelGGL(resid_dual_kernel, dim3(128), dim3(256), 0, s, nx, d.x, d.rhs, d.scal);
+  QP_LAUNCHED(qp);
+  SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->h_scal, d.scal, SL_COUNT * sizeof(double), hipMemcpyDeviceToHost, s));
+  SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  return SCP_OK;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------------------
+// C-ABI
+// ----------------------------------------------------------------------------------------------------
+extern "C" void scp_qp_default_settings(scp_qp_settings* s) {
+  if (!s) return;
+  s->rho = 0.1;
+  s->sigma = 1e-6;
+  s->alpha = 1.6;
+  s->rho_eq_scale = 1e3;
+  s->eps_abs = 1e-3;
+  s->eps_rel = 1e-3;
+  s->max_iter = 4000;
+  s->check_termination = 25;
+  s->adaptive_rho = 1;
+  s->adaptive_rho_interval = 25;
+  s->adaptive_rho_tolerance = 5.0;
+  s->cg_iters = 5;
+  s->use_mfma = 1;
+}
+
+extern "C" size_t scp_qp_workspace_bytes(int N, int K, int D, int64_t row_capacity) {
+  if (N <= 0 || K <= 1 || (D != 2 && D != 3) || row_capacity < 0) return 0;
+  QpDev d;
+  return carve(d, nullptr, K, (int64_t)N * D, row_capacity, D);
+}
+
+static int check_settings(scp_ctx* ctx, const scp_qp_settings* s) {
+  SCP_REQUIRE(ctx, s->rho > 0 && s->sigma > 0 && s->alpha > 0 && s->alpha < 2 && s->rho_eq_scale > 0,
+              "qp settings: rho/sigma/alpha out of range");
+  SCP_REQUIRE(ctx, s->max_iter > 0 && s->check_termination > 0 && s->cg_iters >= 0, "qp settings: bad iteration counts");
+  return SCP_OK;
+}
+
+extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const scp_qp_settings* s, void* workspace,
+                             size_t workspace_bytes, int64_t row_capacity, scp_qp** out) {
+  if (!ctx) return SCP_ERR_INVALID;
+  SCP_REQUIRE(ctx, out && s && workspace, "qp_create: null pointer");
+  SCP_REQUIRE(ctx, N > 0 && K > 1 && (D == 2 || D == 3) && h > 0 && row_capacity >= 0, "qp_create: bad shape");
+  SCP_REQUIRE(ctx, (uintptr_t)workspace % 256 == 0, "qp_create: workspace must be 256-byte aligned");
+  int rc = check_settings(ctx, s);
+  if (rc) return rc;
+  const size_t need = scp_qp_workspace_bytes(N, K, D, row_capacity);
+  if (workspace_bytes < need)
+    return scp_fail(ctx, SCP_ERR_CAPACITY, "qp_create: workspace %zu < %zu bytes", workspace_bytes, need);
+  scp_qp* qp = new scp_qp();
+  qp->ctx = ctx;
+  qp->N = N; qp->K = K; qp->D = D; qp->Rf = 4 * K - 1; qp->C = (int64_t)N * D; qp->h = h;
+  qp->st = *s;
+  qp->row_cap = row_capacity;
+  qp->nW = 0;
+  qp->problem_set = qp->reset_done = false;
+  qp->rho = s->rho;
+  carve(qp->d, workspace, K, qp->C, row_capacity, D);
+  if (hipHostMalloc(&qp->h_scal, SL_COUNT * sizeof(double)) != hipSuccess) {
+    delete qp;
+    return scp_fail(ctx, SCP_ERR_HIP, "qp_create: hipHostMalloc failed");
+  }
+  // constant blocks (scp.py:10-28, :198-203, :227-232, :489-491), built on the host once per (K, h)
+  const int Rf = qp->Rf;
+  std::vector<double> F((size_t)Rf * K, 0.0), Ft((size_t)Rf * K, 0.0), S0((size_t)K * K, 0.0), S0t((size_t)K * K, 0.0),
+      w(Rf, 1.0);
+  const double hh = h * h;
+  for (int k = 0; k < K - 1; ++k) {  // jerk
+    F[(size_t)k * K + k] = -1.0 / h;
+    F[(size_t)k * K + k + 1] = 1.0 / h;
+  }
+  for (int k = 0; k < K; ++k) {
+    F[(size_t)(K - 1 + k) * K + k] = 1.0;                                           // acc
+    for (int m = 0; m <= k; ++m) F[(size_t)(2 * K - 1 + k) * K + m] = h;              // vel (state k+1)
+    for (int m = 0; m <= k; ++m) F[(size_t)(3 * K - 1 + k) * K + m] = hh * (k - m + 0.5);  // pos (state k+1)
+    for (int m = 0; m < k; ++m) S0[(size_t)k * K + m] = hh * (k - m - 0.5);           // stored sample k
+  }
+  for (int r = 0; r < Rf; ++r)
+    for (int m = 0; m < K; ++m) Ft[(size_t)m * Rf + r] = F[(size_t)r * K + m];
+  for (int k = 0; k < K; ++k)
+    for (int m = 0; m < K; ++m) S0t[(size_t)m * K + k] = S0[(size_t)k * K + m];
+  w[2 * K - 1 + K - 1] = s->rho_eq_scale;  // final velocity equality (scp.py:223-224)
+  w[3 * K - 1 + K - 1] = s->rho_eq_scale;  // final position equality (scp.py:256-257)
+  hipStream_t st = ctx->stream;
+  const QpDev& d = qp->d;
+  bool ok = hipMemcpyAsync(d.F, F.data(), F.size() * 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+            hipMemcpyAsync(d.Ft, Ft.data(), Ft.size() * 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+            hipMemcpyAsync(d.S0, S0.data(), S0.size() * 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+            hipMemcpyAsync(d.S0t, S0t.data(), S0t.size() * 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+            hipMemcpyAsync(d.wrow, w.data(), w.size() * 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+            hipStreamSynchronize(st) == hipSuccess;
+  if (!ok) {
+    (void)hipHostFree(qp->h_scal);
+    delete qp;
+    return scp_fail(ctx, SCP_ERR_HIP, "qp_create: constant upload failed");
+  }
+  *out = qp;
+  return SCP_OK;
+}
+
+extern "C" void scp_qp_destroy(scp_qp* qp) {
+  if (!qp) return;
+  (void)hipStreamSynchronize(qp->ctx->stream);
+  (void)hipHostFree(qp->h_scal);
+  delete qp;
+}
+
+extern "C" int scp_qp_update_settings(scp_qp* qp, const scp_qp_settings* s) {
+  if (!qp || !s) return SCP_ERR_INVALID;
+  int rc = check_settings(qp->ctx, s);
+  if (rc) return rc;
+  SCP_REQUIRE(qp->ctx, s->rho_eq_scale == qp->st.rho_eq_scale, "qp_update_settings: rho_eq_scale is fixed at create");
+  qp->st = *s;
+  return SCP_OK;
+}
+
+extern "C" int scp_qp_set_problem(scp_qp* qp, const double* limits, const double* space, const double* p0,
+                                  const double* v0, const double* pf, const double* vf) {
+  if (!qp) return SCP_ERR_INVALID;
+  SCP_REQUIRE(qp->ctx, limits && space && p0 && v0 && pf && vf, "qp_set_problem: null pointer");
+  QP_CHECK(scp_launch_bounds_time_major(qp->ctx, qp->N, qp->K, qp->D, qp->h, limits, space, p0, v0, pf, vf, qp->d.lf,
+                                        qp->d.uf));
+  qp->problem_set = true;
+  qp->reset_done = false;
+  return SCP_OK;
+}
+
+extern "C" int scp_qp_reset(scp_qp* qp, const double* x0) {
+  if (!qp) return SCP_ERR_INVALID;
+  scp_ctx* ctx = qp->ctx;
+  if (!qp->problem_set) return scp_fail(ctx, SCP_ERR_STATE, "qp_reset: call scp_qp_set_problem first");
+  const QpDev& d = qp->d;
+  const int64_t nx = (int64_t)qp->K * qp->C, nf = (int64_t)qp->Rf * qp->C;
+  if (x0) QP_CHECK(scp_launch_to_time_major(ctx, qp->N, qp->K, qp->D, x0, d.x));
+  else SCP_HIP_CHECK(ctx, hipMemsetAsync(d.x, 0, nx * sizeof(double), ctx->stream));
+  QP_CHECK(gemm(qp, qp->Rf, qp->K, 1.0, d.F, d.x, 0.0, d.zf));  // z = A x  (primal warm start, scp.py:443)
+  SCP_HIP_CHECK(ctx, hipMemsetAsync(d.yf, 0, nf * sizeof(double), ctx->stream));
+  qp->nW = 0;
+  qp->rho = qp->st.rho;
+  QP_CHECK(build_kkt(qp));
+  qp->reset_done = true;
+  return SCP_OK;
+}
+
+extern "C" int scp_qp_add_rows(scp_qp* qp, int64_t n, const int64_t* rows, const double* w_eta, const double* w_l) {
+  if (!qp) return SCP_ERR_INVALID;
+  scp_ctx* ctx = qp->ctx;
+  if (!qp->reset_done) return scp_fail(ctx, SCP_ERR_STATE, "qp_add_rows: call scp_qp_reset first");
+  if (n <= 0) return SCP_OK;
+  SCP_REQUIRE(ctx, rows && w_eta && w_l, "qp_add_rows: null pointer");
+  if (qp->nW + n > qp->row_cap)
+    return scp_fail(ctx, SCP_ERR_CAPACITY, "qp_add_rows: %lld + %lld rows exceed the capacity %lld",
+                    (long long)qp->nW, (long long)n, (long long)qp->row_cap);
+  const QpDev& d = qp->d;
+  const int64_t nx = (int64_t)qp->K * qp->C;
+  QP_CHECK(gemm(qp, qp->K, qp->K, 1.0, d.S0, d.x, 0.0, d.HQ + nx));
+  hipLaunchKernelGGL(add_rows_kernel, grid1(n), dim3(256), 0, ctx->stream, qp->N, qp->D, qp->C, scp_pairs(qp->N),
+                     qp->nW, n, rows, w_eta, w_l, d.HQ + nx, d.w_row, d.w_k, d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc);
+  QP_LAUNCHED(qp);
+  qp->nW += n;
+  return SCP_OK;
+}
+
+extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
+  if (!qp) return SCP_ERR_INVALID;
+  scp_ctx* ctx = qp->ctx;
+  if (!qp->reset_done) return scp_fail(ctx, SCP_ERR_STATE, "qp_solve: call scp_qp_reset first");
+  SCP_REQUIRE(ctx, info, "qp_solve: null info");
+  const scp_qp_settings& st = qp->st;
+  memset(info, 0, sizeof(*info));
+  info->status_val = -2;  // OSQP_MAX_ITER_REACHED
+  SCP_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  int cg_total = 0, it = 0;
+  double rp = INFINITY, rd = INFINITY;
+  while (it < st.max_iter) {
+    ++it;
+    QP_CHECK(admm_iteration(qp, &cg_total));
+    if (it % st.check_termination == 0 || it >= st.max_iter) {
+      QP_CHECK(residuals(qp));
+      const double* hs = qp->h_scal;
+      rp = hs[SL_RP];
+      rd = hs[SL_RD];
+      const double np = fmax(hs[SL_NAX], hs[SL_NZ]);
+      const double nd = fmax(hs[SL_NPX], hs[SL_NATY]);
+      if (rp <= st.eps_abs + st.eps_rel * np && rd <= st.eps_abs + st.eps_rel * nd) {
+        info->status_val = 1;
+        break;
+      }
+      if (st.adaptive_rho && st.adaptive_rho_interval > 0 && it % st.adaptive_rho_interval == 0) {
+        const double prim = rp / fmax(np, 1e-10);
+        const double dual = rd / fmax(nd, 1e-10);
+        double nr = qp->rho * std::sqrt(prim / fmax(dual, 1e-10));
+        nr = fmin(fmax(nr, 1e-6), 1e6);
+        if (nr > qp->rho * st.adaptive_rho_tolerance || nr < qp->rho / st.adaptive_rho_tolerance) {
+          qp->rho = nr;
+          QP_CHECK(build_kkt(qp));
+          ++info->rho_updates;
+        }
+      }
+    }
+  }
+  SCP_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  SCP_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  SCP_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  info->iter = it;
+  info->cg_iters_total = cg_total;
+  info->working_rows = qp->nW;
+  info->r_prim = rp;
+  info->r_dual = rd;
+  info->rho = qp->rho;
+  info->solve_ms = ms;
+  return SCP_OK;
+}
+
+extern "C" int scp_qp_get_solution(scp_qp* qp, double* x_out) {
+  if (!qp) return SCP_ERR_INVALID;
+  SCP_REQUIRE(qp->ctx, x_out, "qp_get_solution: null pointer");
+  if (!qp->reset_done) return scp_fail(qp->ctx, SCP_ERR_STATE, "qp_get_solution: no solve yet");
+  return scp_launch_from_time_major(qp->ctx, qp->N, qp->K, qp->D, qp->d.x, x_out);
+}
+
+extern "C" int scp_qp_get_duals(scp_qp* qp, double* y_fixed, double* y_col) {
+  if (!qp) return SCP_ERR_INVALID;
+  scp_ctx* ctx = qp->ctx;
+  if (!qp->reset_done) return scp_fail(ctx, SCP_ERR_STATE, "qp_get_duals: no solve yet");
+  const int N = qp->N, K = qp->K, D = qp->D;
+  const int64_t C = qp->C;
+  if (y_fixed) {
+    // blocks back to the reference stacking order (scp.py:342-358)
+    QP_CHECK(scp_launch_from_time_major(ctx, N, K - 1, D, qp->d.yf, y_fixed));
+    int64_t src = (int64_t)(K - 1) * C, dst = (int64_t)N * (K - 1) * D;
+    for (int b = 0; b < 3; ++b) {
+      QP_CHECK(scp_launch_from_time_major(ctx, N, K, D, qp->d.yf + src, y_fixed + dst));
+      src += (int64_t)K * C;
+      dst += (int64_t)N * K * D;
+    }
+  }
+  if (y_col && qp->nW > 0)
+    SCP_HIP_CHECK(ctx, hipMemcpyAsync(y_col, qp->d.yc, qp->nW * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  return SCP_OK;
+}

@@ -1,0 +1,371 @@
+"""ctypes binding of libscp_hip.so (include/scp_hip.h) -- the only door from Python to the GPU code.
+
+PyTorch-ROCm is used for device memory and streams only: every pointer handed to the library is the
+``data_ptr()`` of a torch tensor on ``cuda:<device>`` and all kernels are enqueued on torch's current
+stream.  There is NO CPU fallback: if the shared library or a GPU is missing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_LIB = None
+_LIB_PATH = None
+
+SCP_OK = 0
+SCP_ERR_CAPACITY = -3
+UINT64_MAX = (1 << 64) - 1
+
+STATUS_TEXT = {1: "solved", 2: "solved inaccurate", -2: "maximum iterations reached", -3: "primal infeasible"}
+
+
+class HipError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"libscp_hip error {code}: {text}")
+        self.code = code
+
+
+class QpSettings(C.Structure):
+    """struct scp_qp_settings"""
+
+    _fields_ = [
+        ("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double), ("rho_eq_scale", C.c_double),
+        ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("max_iter", C.c_int32),
+        ("check_termination", C.c_int32), ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32),
+        ("adaptive_rho_tolerance", C.c_double), ("cg_iters", C.c_int32), ("use_mfma", C.c_int32),
+    ]
+
+
+class QpInfo(C.Structure):
+    """struct scp_qp_info"""
+
+    _fields_ = [
+        ("status_val", C.c_int32), ("iter", C.c_int32), ("rho_updates", C.c_int32), ("cg_iters_total", C.c_int32),
+        ("working_rows", C.c_int64), ("r_prim", C.c_double), ("r_dual", C.c_double), ("rho", C.c_double),
+        ("solve_ms", C.c_double),
+    ]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["status"] = STATUS_TEXT.get(self.status_val, str(self.status_val))
+        return d
+
+
+EXPORTS = [
+    "scp_abi_version", "scp_ctx_create", "scp_ctx_destroy", "scp_last_error", "scp_ctx_synchronize",
+    "scp_kinematics", "scp_fixed_bounds", "scp_linearize_pairs", "scp_check_avoidance",
+    "scp_collision_violations", "scp_gather_rows", "scp_rel_step", "scp_qp_default_settings",
+    "scp_qp_workspace_bytes", "scp_qp_create", "scp_qp_destroy", "scp_qp_update_settings", "scp_qp_set_problem",
+    "scp_qp_reset", "scp_qp_add_rows", "scp_qp_solve", "scp_qp_get_solution", "scp_qp_get_duals", "scp_gemm_f64",
+]
+
+
+def library_path():
+    env = os.environ.get("SCP_HIP_LIB")
+    if env:
+        return env
+    here = os.path.dirname(os.path.abspath(__file__))
+    return os.path.join(os.path.dirname(here), "lib", "libscp_hip.so")
+
+
+def load_library():
+    """dlopen libscp_hip.so and declare the prototypes.  Raises if it is missing: the product path has no
+    fallback (build it with ``python -c 'import __graft_entry__ as g; g.build()'`` or ``make -C csrc``)."""
+    global _LIB, _LIB_PATH
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise HipError(-100, f"{path} not found: build the HIP extension first (make -C ba-path-planning_amd/csrc)")
+    lib = C.CDLL(path)
+    vp, i32, i64, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
+    pd = C.POINTER(C.c_double)
+    lib.scp_abi_version.restype = i32
+    lib.scp_ctx_create.argtypes = [i32, vp, C.POINTER(vp)]
+    lib.scp_ctx_destroy.argtypes = [vp]
+    lib.scp_ctx_destroy.restype = None
+    lib.scp_last_error.argtypes = [vp]
+    lib.scp_last_error.restype = C.c_char_p
+    lib.scp_ctx_synchronize.argtypes = [vp]
+    lib.scp_kinematics.argtypes = [vp, i32, i32, i32, f64, vp, vp, vp, vp, vp]
+    lib.scp_fixed_bounds.argtypes = [vp, i32, i32, i32, f64, pd, pd, vp, vp, vp, vp, vp, vp]
+    lib.scp_linearize_pairs.argtypes = [vp, i32, i32, i32, f64, f64, i64, i64, vp, vp, vp, vp, vp, f64, vp, i64, vp, vp]
+    lib.scp_check_avoidance.argtypes = [vp, i32, i32, i32, f64, i64, i64, vp, vp]
+    lib.scp_collision_violations.argtypes = [vp, i32, i32, i32, f64, i64, i64, vp, vp, vp, vp, vp, f64, vp, i64, vp, vp]
+    lib.scp_gather_rows.argtypes = [vp, i32, i32, i32, i64, i64, vp, vp, vp, i64, vp, vp]
+    lib.scp_rel_step.argtypes = [vp, i64, vp, vp, pd]
+    lib.scp_qp_default_settings.argtypes = [C.POINTER(QpSettings)]
+    lib.scp_qp_default_settings.restype = None
+    lib.scp_qp_workspace_bytes.argtypes = [i32, i32, i32, i64]
+    lib.scp_qp_workspace_bytes.restype = sz
+    lib.scp_qp_create.argtypes = [vp, i32, i32, i32, f64, C.POINTER(QpSettings), vp, sz, i64, C.POINTER(vp)]
+    lib.scp_qp_destroy.argtypes = [vp]
+    lib.scp_qp_destroy.restype = None
+    lib.scp_qp_update_settings.argtypes = [vp, C.POINTER(QpSettings)]
+    lib.scp_qp_set_problem.argtypes = [vp, pd, pd, vp, vp, vp, vp]
+    lib.scp_qp_reset.argtypes = [vp, vp]
+    lib.scp_qp_add_rows.argtypes = [vp, i64, vp, vp, vp]
+    lib.scp_qp_solve.argtypes = [vp, C.POINTER(QpInfo)]
+    lib.scp_qp_get_solution.argtypes = [vp, vp]
+    lib.scp_qp_get_duals.argtypes = [vp, vp, vp]
+    lib.scp_gemm_f64.argtypes = [vp, i32, i32, i32, i32, f64, vp, vp, f64, vp]
+    _LIB, _LIB_PATH = lib, path
+    return lib
+
+
+def default_settings(**overrides) -> QpSettings:
+    s = QpSettings()
+    load_library().scp_qp_default_settings(C.byref(s))
+    for k, v in overrides.items():
+        if not hasattr(s, k):
+            raise TypeError(f"unknown QP setting {k!r}")
+        setattr(s, k, v)
+    return s
+
+
+def eta_stride(K, nq):
+    return (K * nq + 1) & ~1
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _harr(values):
+    a = np.ascontiguousarray(values, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Context:
+    """scp_ctx bound to ``cuda:<device>`` and to torch's current stream on it."""
+
+    def __init__(self, device=0):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise HipError(-101, "no GPU visible: the SCP hot path runs on MI355X only (there is no CPU fallback)")
+        self.lib = load_library()
+        self.device = int(device)
+        self.tdev = torch.device("cuda", self.device)
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.tdev).cuda_stream
+        h = C.c_void_p()
+        rc = self.lib.scp_ctx_create(self.device, C.c_void_p(stream), C.byref(h))
+        if rc != SCP_OK:
+            raise HipError(rc, "scp_ctx_create failed")
+        self.h = h
+        self.stats = torch.zeros(4, dtype=torch.float64, device=self.tdev)  # struct scp_pair_stats
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.scp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers -------------------------------------------------------------------------------
+    def check(self, rc):
+        if rc != SCP_OK:
+            raise HipError(rc, self.lib.scp_last_error(self.h).decode())
+
+    def tensor(self, array):
+        torch = _torch()
+        return torch.as_tensor(np.ascontiguousarray(array, dtype=np.float64)).to(self.tdev)
+
+    def empty(self, *shape, dtype=None):
+        torch = _torch()
+        return torch.empty(*shape, dtype=dtype or torch.float64, device=self.tdev)
+
+    def read_stats(self):
+        """(min_dist, first_violation, n_selected, max_violation) -- synchronises."""
+        torch = _torch()
+        raw = self.stats.cpu().numpy()
+        u = raw.view(np.uint64)
+        return float(raw[0]), int(u[1]), int(u[2]), float(raw[3])
+
+    # ---- stateless entry points --------------------------------------------------------------------
+    def kinematics(self, N, K, D, h, acc, p0, v0, want_vel=True):
+        pos = self.empty(N, K, D)
+        vel = self.empty(N, K, D) if want_vel else None
+        self.check(self.lib.scp_kinematics(self.h, N, K, D, h, acc.data_ptr(), p0.data_ptr(), v0.data_ptr(),
+                                           pos.data_ptr(), vel.data_ptr() if want_vel else None))
+        return pos, vel
+
+    def fixed_bounds(self, N, K, D, h, limits, space, p0, v0, pf, vf):
+        m = N * D * (4 * K - 1)
+        lo, hi = self.empty(m), self.empty(m)
+        la, lp = _harr(limits)
+        sa, sp = _harr(space)
+        self.check(self.lib.scp_fixed_bounds(self.h, N, K, D, h, lp, sp, p0.data_ptr(), v0.data_ptr(), pf.data_ptr(),
+                                             vf.data_ptr(), lo.data_ptr(), hi.data_ptr()))
+        return lo, hi
+
+    def check_avoidance(self, N, K, D, R, pos, q_begin=0, q_end=None):
+        q_end = N * (N - 1) // 2 if q_end is None else q_end
+        self.check(self.lib.scp_check_avoidance(self.h, N, K, D, R, q_begin, q_end, pos.data_ptr(),
+                                                self.stats.data_ptr()))
+        return self.read_stats()
+
+    def rel_step(self, a_new, a_prev):
+        out = (C.c_double * 3)()
+        self.check(self.lib.scp_rel_step(self.h, a_new.numel(), a_new.data_ptr(), a_prev.data_ptr(), out))
+        return float(out[0]), float(out[1]), float(out[2])
+
+    def gemm(self, A, X, use_mfma=True, alpha=1.0, beta=0.0, Y=None):
+        R, M = A.shape
+        M2, Cc = X.shape
+        assert M == M2
+        if Y is None:
+            Y = self.empty(R, Cc)
+            Y.zero_()
+        self.check(self.lib.scp_gemm_f64(self.h, int(use_mfma), R, M, Cc, alpha, A.data_ptr(), X.data_ptr(), beta,
+                                         Y.data_ptr()))
+        return Y
+
+
+class PairPass:
+    """Buffers + calls of the O(N^2 K) passes for the pair range [q_begin, q_end) (one rank's shard)."""
+
+    def __init__(self, ctx: Context, N, K, D, R, h, q_begin=0, q_end=None, sel_cap=None):
+        torch = _torch()
+        self.ctx, self.N, self.K, self.D, self.R, self.h = ctx, N, K, D, R, h
+        self.pairs = N * (N - 1) // 2
+        self.q_begin = q_begin
+        self.q_end = self.pairs if q_end is None else q_end
+        self.nq = self.q_end - self.q_begin
+        self.rows = self.K * self.nq
+        self.stride = eta_stride(K, self.nq)
+        self.eta = ctx.empty(max(D * self.stride, 2))
+        self.l = ctx.empty(max(self.rows + (self.rows & 1), 2))
+        self.bitmap = torch.zeros(max((self.rows + 31) // 32, 1), dtype=torch.int32, device=ctx.tdev)
+        self.sel_cap = int(sel_cap if sel_cap is not None else min(max(self.rows, 1), max(65536, 64 * N * K)))
+        self.sel = torch.empty(self.sel_cap, dtype=torch.int64, device=ctx.tdev)
+
+    def _grow(self, need):
+        torch = _torch()
+        self.sel_cap = int(min(max(self.rows, 1), max(need, 2 * self.sel_cap)))
+        self.sel = torch.empty(self.sel_cap, dtype=torch.int64, device=self.ctx.tdev)
+
+    def linearize(self, pos_prev, p0, v0, margin):
+        """a5: fills eta/l, returns (rows tensor (n,), min_dist, first_violation)."""
+        c = self.ctx
+        while True:
+            c.check(c.lib.scp_linearize_pairs(c.h, self.N, self.K, self.D, self.R, self.h, self.q_begin, self.q_end,
+                                              pos_prev.data_ptr(), p0.data_ptr(), v0.data_ptr(), self.eta.data_ptr(),
+                                              self.l.data_ptr(), margin, self.sel.data_ptr(), self.sel_cap,
+                                              self.bitmap.data_ptr(), c.stats.data_ptr()))
+            min_dist, first, n_sel, _ = c.read_stats()
+            if n_sel <= self.sel_cap:
+                return self.sel[:n_sel].clone(), min_dist, first
+            self._grow(n_sel)
+
+    def violations(self, pos_new, p0, v0, feas_tol):
+        """rows outside the working set violated at pos_new -> (rows tensor, max_violation)."""
+        c = self.ctx
+        torch = _torch()
+        while True:
+            snapshot = self.bitmap.clone()
+            c.check(c.lib.scp_collision_violations(c.h, self.N, self.K, self.D, self.h, self.q_begin, self.q_end,
+                                                   self.eta.data_ptr(), self.l.data_ptr(), pos_new.data_ptr(),
+                                                   p0.data_ptr(), v0.data_ptr(), feas_tol, self.sel.data_ptr(),
+                                                   self.sel_cap, self.bitmap.data_ptr(), c.stats.data_ptr()))
+            _, _, n_sel, max_v = c.read_stats()
+            if n_sel <= self.sel_cap:
+                return self.sel[:n_sel].clone(), max_v
+            self.bitmap.copy_(snapshot)
+            self._grow(n_sel)
+
+    def gather(self, rows):
+        c = self.ctx
+        n = int(rows.numel())
+        w_eta = c.empty(max(n, 1), self.D)
+        w_l = c.empty(max(n, 1))
+        if n:
+            c.check(c.lib.scp_gather_rows(c.h, self.N, self.K, self.D, self.q_begin, self.q_end, self.eta.data_ptr(),
+                                          self.l.data_ptr(), rows.data_ptr(), n, w_eta.data_ptr(), w_l.data_ptr()))
+        return w_eta[:n], w_l[:n]
+
+    # views in the reference's row order (local rows)
+    def eta_rows(self):
+        return self.eta[: self.D * self.stride].view(self.D, self.stride)[:, : self.rows].t()
+
+    def l_rows(self):
+        return self.l[: self.rows]
+
+
+class QP:
+    """scp_qp: the joint QP on the fixed rows + a working set of collision rows."""
+
+    def __init__(self, ctx: Context, N, K, D, h, settings: QpSettings | None = None, row_capacity=None):
+        torch = _torch()
+        self.ctx, self.N, self.K, self.D, self.h = ctx, N, K, D, h
+        self.settings = settings or default_settings()
+        m_col = K * N * (N - 1) // 2
+        self.row_capacity = int(row_capacity if row_capacity is not None else min(m_col, max(8192, 32 * N * K)))
+        nbytes = ctx.lib.scp_qp_workspace_bytes(N, K, D, self.row_capacity)
+        if nbytes == 0:
+            raise HipError(-1, f"bad QP shape N={N} K={K} D={D}")
+        self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=ctx.tdev)
+        off = (-self.workspace.data_ptr()) % 256
+        self._ws_ptr = self.workspace.data_ptr() + off
+        h_ = C.c_void_p()
+        ctx.check(ctx.lib.scp_qp_create(ctx.h, N, K, D, h, C.byref(self.settings), C.c_void_p(self._ws_ptr), nbytes,
+                                        self.row_capacity, C.byref(h_)))
+        self.h_qp = h_
+        self.n_rows = 0
+
+    def close(self):
+        if getattr(self, "h_qp", None) and getattr(self.ctx, "h", None):
+            self.ctx.lib.scp_qp_destroy(self.h_qp)
+        self.h_qp = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update_settings(self, **kw):
+        for k, v in kw.items():
+            setattr(self.settings, k, v)
+        self.ctx.check(self.ctx.lib.scp_qp_update_settings(self.h_qp, C.byref(self.settings)))
+
+    def set_problem(self, limits, space, p0, v0, pf, vf):
+        la, lp = _harr(limits)
+        sa, sp = _harr(space)
+        self.ctx.check(self.ctx.lib.scp_qp_set_problem(self.h_qp, lp, sp, p0.data_ptr(), v0.data_ptr(), pf.data_ptr(),
+                                                       vf.data_ptr()))
+
+    def reset(self, x0=None):
+        self.ctx.check(self.ctx.lib.scp_qp_reset(self.h_qp, x0.data_ptr() if x0 is not None else None))
+        self.n_rows = 0
+
+    def add_rows(self, rows, w_eta, w_l):
+        n = int(rows.numel())
+        if n == 0:
+            return
+        self.ctx.check(self.ctx.lib.scp_qp_add_rows(self.h_qp, n, rows.data_ptr(), w_eta.data_ptr(), w_l.data_ptr()))
+        self.n_rows += n
+
+    def solve(self):
+        info = QpInfo()
+        self.ctx.check(self.ctx.lib.scp_qp_solve(self.h_qp, C.byref(info)))
+        return info.as_dict()
+
+    def solution(self):
+        x = self.ctx.empty(self.N, self.K, self.D)
+        self.ctx.check(self.ctx.lib.scp_qp_get_solution(self.h_qp, x.data_ptr()))
+        return x
+
+    def duals(self):
+        yf = self.ctx.empty(self.N * self.D * (4 * self.K - 1))
+        yc = self.ctx.empty(max(self.n_rows, 1))
+        self.ctx.check(self.ctx.lib.scp_qp_get_duals(self.h_qp, yf.data_ptr(), yc.data_ptr()))
+        return yf, yc[: self.n_rows]

@@ -1,0 +1,123 @@
+"""Scenario generation for the SCP planner (host side).
+
+Two generators:
+
+* ``generate_positions`` -- the reference layout (corner circles -> central diamond) with the same
+  sampling sequence as /root/reference/src/path_planning/scenarios/position_generator.py:44-75,
+  :235-248, so that ``random.seed(s)`` (or the new ``seed=`` argument, which the reference leaves as
+  a TODO at compute_trajectories_batch.py:40) reproduces the reference's scenarios bit for bit
+  (tests/test_scenarios.py against tests/golden/ref_generator.npz).  Capacity at R = 0.8 is about
+  56 agents; beyond that it raises ``ValueError`` like the reference.
+* ``generate_grid_swap`` -- synthetic scenarios for N >= 64: starts on a
+  jittered grid, goals = starts permuted inside blocks of ``block`` x ``block`` agents, so that every
+  displacement stays feasible for |v| <= 2 m/s, T = 10 s.  D = 2 or 3.
+"""
+import math
+import random as _random
+
+import numpy as np
+
+BOX_SIZE = 20.0
+CIRCLE_RADIUS = 2.5
+CIRCLE_CENTERS = np.array([[3.5, 3.5], [16.5, 3.5], [3.5, 16.5], [16.5, 16.5]])
+DIAMOND_CENTER = np.array([10.0, 10.0])
+DIAMOND_SIDE = 6.0
+_HALF_DIAG = DIAMOND_SIDE / np.sqrt(2)
+DIAMOND_VERTICES = DIAMOND_CENTER + _HALF_DIAG * np.array([[0.0, 1.0], [1.0, 0.0], [0.0, -1.0], [-1.0, 0.0]])
+
+
+class _Sampler:
+    """Draws from ``rng`` in the reference's order: circle = randint(0,3) then uniform(0, 2pi);
+    diamond = randint(0,3) then uniform(0,1); goal kind = random() < 0.9."""
+
+    def __init__(self, rng):
+        self.rng = rng
+
+    def on_circle(self):
+        c = CIRCLE_CENTERS[self.rng.randint(0, 3)]
+        ang = self.rng.uniform(0, 2 * np.pi)
+        return c + CIRCLE_RADIUS * np.array([np.cos(ang), np.sin(ang)])
+
+    def on_diamond(self):
+        e = self.rng.randint(0, 3)
+        a, b = DIAMOND_VERTICES[e], DIAMOND_VERTICES[(e + 1) % 4]
+        t = self.rng.uniform(0, 1)
+        return a + t * (b - a)
+
+    def goal(self):
+        if self.rng.random() < 0.9:
+            return self.on_diamond()
+        return self.on_circle()
+
+
+def _far_enough(p, chosen, min_dist):
+    return all(np.linalg.norm(p - c) >= min_dist for c in chosen)
+
+
+def _rejection(draw, n, min_dist, max_attempts, what):
+    chosen = []
+    for _ in range(max_attempts):
+        if len(chosen) == n:
+            break
+        cand = draw()
+        if _far_enough(cand, chosen, min_dist):
+            chosen.append(cand)
+    if len(chosen) < n:
+        raise ValueError(f"Could not generate enough {what} positions.")
+    return np.array(chosen)
+
+
+def generate_positions(n_vehicles, min_distance=0.4, max_attempts=1000, seed=None):
+    """(initial (N,2), final (N,2)).  seed=None draws from the global ``random`` module like the
+    reference; an int seed uses a private ``random.Random(seed)`` (same stream as random.seed(seed))."""
+    rng = _random if seed is None else _random.Random(seed)
+    s = _Sampler(rng)
+    initial = _rejection(s.on_circle, n_vehicles, min_distance, max_attempts, "initial")
+    final = _rejection(s.goal, n_vehicles, min_distance, max_attempts, "final")
+    return initial, final
+
+
+def generate_grid_swap(n_agents, seed=0, pitch=2.0, jitter=0.2, block=4, dim=2, layer_gap=2.0):
+    """Synthetic scenario for large N.  Returns (initial (N,dim), final (N,dim), space_dims).
+
+    dim=2: agents on a ceil(sqrt(N))^2 grid; dim=3: ceil(cbrt(N)) layers ``layer_gap`` apart, each a
+    2-D grid.  Goals are the starts under a seeded permutation inside ``block`` x ``block`` cells
+    (within a layer), so the displacement is at most (block-1)*pitch*sqrt(2) + 2*jitter*sqrt(2).
+    space_dims = [min_0.., max_0..] with a 2 m rim."""
+    rng = np.random.default_rng(seed)
+    if dim == 2:
+        layers, per = 1, n_agents
+    elif dim == 3:
+        layers = max(1, math.ceil(round(n_agents ** (1.0 / 3.0), 9)))
+        per = math.ceil(n_agents / layers)
+    else:
+        raise ValueError("dim must be 2 or 3")
+    side = math.ceil(math.sqrt(per))
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side), indexing="ij")
+    cells = np.stack([gx.ravel(), gy.ravel()], axis=1)
+    init = []
+    goal = []
+    remaining = n_agents
+    for L in range(layers):
+        cnt = min(per, remaining)
+        remaining -= cnt
+        cell = cells[:cnt]
+        xy = cell * pitch + rng.uniform(-jitter, jitter, size=(cnt, 2))
+        # permute inside block x block cells
+        key = (cell[:, 0] // block) * (side // block + 1) + (cell[:, 1] // block)
+        tgt = np.arange(cnt)
+        for kk in np.unique(key):
+            idx = np.nonzero(key == kk)[0]
+            tgt[idx] = idx[rng.permutation(idx.size)]
+        gxy = xy[tgt]
+        if dim == 3:
+            z = np.full((cnt, 1), L * layer_gap)
+            xy = np.hstack([xy, z])
+            gxy = np.hstack([gxy, z])
+        init.append(xy)
+        goal.append(gxy)
+    init = np.vstack(init)
+    goal = np.vstack(goal)
+    lo = np.minimum(init.min(axis=0), goal.min(axis=0)) - 2.0
+    hi = np.maximum(init.max(axis=0), goal.max(axis=0)) + 2.0
+    return init, goal, [float(v) for v in lo] + [float(v) for v in hi]

@@ -1,0 +1,180 @@
+/*
+ * scp_hip.h -- C-ABI of the MI355X (gfx950) SCP hot path: libscp_hip.so
+ *
+ * Drop-in boundary for /root/reference/src/path_planning/solvers/scp.py (class SCP).  The reference is
+ * pure Python with no FFI of its own; each entry point below replaces the body of
+ * one reference method and is what a ctypes binding inside that method would call (INTEGRATION.md shows the
+ * stub).  All `double*` / `int64_t*` arguments are DEVICE pointers unless marked [host]; the caller owns
+ * them (torch-ROCm tensors in our host code).  No torch types cross this boundary.
+ *
+ * Conventions
+ *   - boundary arrays use the reference layout: accelerations/positions/velocities are [N][K][D]
+ *     (flat index (i*K + k)*D + d, scp.py:15-26, :168, :581-582); states are [N][D].
+ *   - D is 2 (the reference) or 3 (extension).
+ *   - collision rows are numbered as the reference orders them: r = k*pairs + q, q = lexicographic index of
+ *     (i, j), i < j  (scp.py:487-496); pairs = N(N-1)/2.
+ *   - every function returns 0 on success or a negative scp_status; scp_last_error(ctx) gives the text.
+ *   - all work is enqueued on the ctx's HIP stream; functions that return host values synchronise it.
+ *   - a ctx and the objects created from it must be used from one thread at a time (one ctx per rank).
+ */
+#ifndef SCP_HIP_H
+#define SCP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCP_ABI_VERSION 1
+
+typedef enum scp_status {
+  SCP_OK = 0,
+  SCP_ERR_INVALID = -1,   /* bad argument (shape, NULL pointer, D not in {2,3}) */
+  SCP_ERR_HIP = -2,       /* a HIP runtime call failed */
+  SCP_ERR_CAPACITY = -3,  /* a caller-provided buffer is too small (row capacity, workspace) */
+  SCP_ERR_STATE = -4      /* call order violated (e.g. solve before set_problem) */
+} scp_status;
+
+typedef struct scp_ctx scp_ctx;
+typedef struct scp_qp scp_qp;
+
+/* Result of a pairwise pass; lives in DEVICE memory (32 bytes), written by scp_linearize_pairs,
+ * scp_check_avoidance and scp_collision_violations. */
+typedef struct scp_pair_stats {
+  double min_dist;            /* min over processed rows of ||p_i[k] - p_j[k]|| (before the dist:=1 rule) */
+  uint64_t first_violation;   /* smallest row id with dist < R - 0.01 (scp.py:610), UINT64_MAX if none */
+  uint64_t n_selected;        /* rows appended to the output list (may exceed its capacity: then only the
+                                 first `capacity` were stored and the call returned SCP_ERR_CAPACITY) */
+  double max_violation;       /* scp_collision_violations: max over rows of l_r - (A x)_r */
+} scp_pair_stats;
+
+/* Settings of the QP solver.  Defaults (scp_qp_default_settings) are OSQP's, because the reference calls
+ * osqp with its defaults (scp.py:360) resp. max_iter=10000 (scp.py:442). */
+typedef struct scp_qp_settings {
+  double rho;                    /* 0.1 */
+  double sigma;                  /* 1e-6 */
+  double alpha;                  /* 1.6 */
+  double rho_eq_scale;           /* 1e3: rho multiplier on equality rows */
+  double eps_abs;                /* 1e-3 */
+  double eps_rel;                /* 1e-3 */
+  int32_t max_iter;              /* 4000 (QP#0, scp.py:360) / 10000 (scp.py:442) */
+  int32_t check_termination;     /* 25 */
+  int32_t adaptive_rho;          /* 1 */
+  int32_t adaptive_rho_interval; /* 25 (iterations; multiple of check_termination) */
+  double adaptive_rho_tolerance; /* 5 */
+  int32_t cg_iters;              /* PCG iterations per ADMM step (fixed count, warm started) */
+  int32_t use_mfma;              /* 1: v_mfma_f64_16x16x4_f64 tiles for the dense K x K products; 0: VALU */
+} scp_qp_settings;
+
+/* [host] result of scp_qp_solve */
+typedef struct scp_qp_info {
+  int32_t status_val;   /* OSQP codes: 1 solved, -2 maximum iterations reached */
+  int32_t iter;         /* ADMM iterations of this call */
+  int32_t rho_updates;
+  int32_t cg_iters_total;
+  int64_t working_rows;
+  double r_prim, r_dual;
+  double rho;
+  double solve_ms;      /* device time of this call (HIP events on the ctx stream) */
+} scp_qp_info;
+
+int scp_abi_version(void);
+
+/* Plane stride (in doubles) of the SoA eta array of scp_linearize_pairs: K*nq rounded up to an even count so
+ * that every plane starts 16-byte aligned. */
+static inline int64_t scp_eta_stride(int64_t K, int64_t nq) { return (K * nq + 1) & ~(int64_t)1; }
+
+/* ---- context -------------------------------------------------------------------------------------- */
+int scp_ctx_create(int device, void* hip_stream /* hipStream_t or NULL for the default stream */, scp_ctx** out);
+void scp_ctx_destroy(scp_ctx* ctx);
+const char* scp_last_error(const scp_ctx* ctx);
+int scp_ctx_synchronize(scp_ctx* ctx);
+
+/* ---- a4 / a7: SCP._compute_positions_velocities (scp.py:371-397),
+ *               SCP._accelerations_to_positions_velocities (scp.py:559-595) ---------------------------
+ * pos[i][k] = p0_i + (h*k) v0_i + sum_{j<k} (h*h*(k-j-0.5)) a_i[j],  vel[i][k] = v0_i + sum_{j<k} h a_i[j],
+ * summed in the reference's order without FMA contraction (bitwise equal to the reference). */
+int scp_kinematics(scp_ctx* ctx, int N, int K, int D, double h, const double* acc, const double* p0,
+                   const double* v0, double* pos_out, double* vel_out);
+
+/* ---- a2: bounds of SCP._precompute_constraint_matrices (scp.py:182-257) -------------------------------
+ * l_out/u_out have N*D*(4K-1) entries in the reference's stacking order jerk, acc, vel, pos (scp.py:342-358).
+ * limits = {vel_min, vel_max, acc_min, acc_max, jerk_min, jerk_max} [host]; space = {min_0..min_{D-1},
+ * max_0..max_{D-1}} [host]. */
+int scp_fixed_bounds(scp_ctx* ctx, int N, int K, int D, double h, const double* limits, const double* space,
+                     const double* p0, const double* v0, const double* pf, const double* vf, double* l_out,
+                     double* u_out);
+
+/* ---- a5 (+a8 fused): SCP._add_collision_constraints (scp.py:453-557) ---------------------------------
+ * Linearises the pairs q in [q_begin, q_end) at every k around pos_prev and writes the COMPACT form of
+ * A_collision / l_collision: eta_out[d*scp_eta_stride(K,nq) + k*nq + (q-q_begin)] (SoA planes, nq = q_end-q_begin,
+ * D*scp_eta_stride doubles, 16-byte aligned) and l_out[k*nq + (q-q_begin)].
+ * Row r of the reference's matrix is  +eta_r[d] h^2 (k-m-.5) on a_i[m], -(same) on a_j[m], m < k; u = +inf.
+ * Degenerate pairs (dist < 1e-6): eta = e_0, dist := 1 (the reference draws a random direction, scp.py:505).
+ * Fused reductions: stats->min_dist, stats->first_violation (dist < R-0.01), and the rows with
+ * dist - R < margin are appended (global row ids r = k*pairs + q) to sel_rows (capacity sel_cap) and marked
+ * in sel_bitmap (one bit per LOCAL row k*nq + (q-q_begin), ceil(K*nq/32) uint32 words, zeroed by this call). */
+int scp_linearize_pairs(scp_ctx* ctx, int N, int K, int D, double R, double h, int64_t q_begin, int64_t q_end,
+                        const double* pos_prev, const double* p0, const double* v0, double* eta_out,
+                        double* l_out, double margin, int64_t* sel_rows, int64_t sel_cap, uint32_t* sel_bitmap,
+                        scp_pair_stats* stats);
+
+/* ---- a8: SCP._fast_check_avoidance_constraints (scp.py:597-615) --------------------------------------
+ * stats->first_violation = first row (k -> i -> j order) with ||p_i - p_j|| < R - 0.01, stats->min_dist. */
+int scp_check_avoidance(scp_ctx* ctx, int N, int K, int D, double R, int64_t q_begin, int64_t q_end,
+                        const double* pos, scp_pair_stats* stats);
+
+/* ---- constraint generation for the joint QP (a6): full pass over the linearised rows ------------------
+ * For every local row not yet marked in sel_bitmap: if (A_col x)_r < l_r - feas_tol, mark it and append its
+ * global id to new_rows.  (A_col x)_r = eta_r . ((pos_i - c_i) - (pos_j - c_j))[k], c = p0 + k h v0,
+ * pos = kinematics(x).  stats->n_selected = rows appended, stats->max_violation. */
+int scp_collision_violations(scp_ctx* ctx, int N, int K, int D, double h, int64_t q_begin, int64_t q_end,
+                             const double* eta, const double* l_col, const double* pos, const double* p0,
+                             const double* v0, double feas_tol, int64_t* new_rows, int64_t new_cap,
+                             uint32_t* sel_bitmap, scp_pair_stats* stats);
+
+/* Gather the compact rows `rows` (global ids, all inside [q_begin,q_end) x K) out of (eta, l_col):
+ * w_eta[n][D] (AoS) and w_l[n]. */
+int scp_gather_rows(scp_ctx* ctx, int N, int K, int D, int64_t q_begin, int64_t q_end, const double* eta,
+                    const double* l_col, const int64_t* rows, int64_t n, double* w_eta, double* w_l);
+
+/* ---- a1: relative step of the SCP loop (scp.py:157-159) ----------------------------------------------
+ * out[0] = ||a_new - a_prev||_2, out[1] = ||a_prev||_2, out[2] = out[0]/out[1] (no zero guard, as the
+ * reference).  out is [host]. */
+int scp_rel_step(scp_ctx* ctx, int64_t n, const double* a_new, const double* a_prev, double* out);
+
+/* ---- a3 / a6 / a9: the joint QP  min ||x||^2  s.t. fixed rows, collision rows -------------------------
+ * Replaces osqp.OSQP().setup/warm_start/solve at scp.py:326-367 and :441-449.  ADMM in OSQP's form with a
+ * matrix-free x-update (PCG preconditioned by the exact inverse of the block-diagonal fixed part), on the
+ * fixed rows plus a working set of collision rows supplied by the caller (exact constraint generation is
+ * driven through scp_collision_violations). */
+void scp_qp_default_settings(scp_qp_settings* s);
+size_t scp_qp_workspace_bytes(int N, int K, int D, int64_t row_capacity);
+int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const scp_qp_settings* s, void* workspace,
+                  size_t workspace_bytes, int64_t row_capacity, scp_qp** out);
+void scp_qp_destroy(scp_qp* qp);
+int scp_qp_update_settings(scp_qp* qp, const scp_qp_settings* s);
+/* bounds of the fixed rows from the problem data (same arithmetic as scp_fixed_bounds) */
+int scp_qp_set_problem(scp_qp* qp, const double* limits /*[host]*/, const double* space /*[host]*/,
+                       const double* p0, const double* v0, const double* pf, const double* vf);
+/* start a new QP: x = x0 ([N][K][D], NULL -> 0), z = A x, y = 0 (primal warm start only, scp.py:443),
+ * empty working set, rho = settings.rho */
+int scp_qp_reset(scp_qp* qp, const double* x0);
+/* append working rows (global ids; eta AoS [n][D]; lower bounds); z = max(A x, l), y = 0 */
+int scp_qp_add_rows(scp_qp* qp, int64_t n, const int64_t* rows, const double* w_eta, const double* w_l);
+int scp_qp_solve(scp_qp* qp, scp_qp_info* info /*[host]*/);
+int scp_qp_get_solution(scp_qp* qp, double* x_out /*[N][K][D]*/);
+/* duals: y_fixed in the reference stacking order (N*D*(4K-1)), y_col per working row (may be NULL) */
+int scp_qp_get_duals(scp_qp* qp, double* y_fixed, double* y_col);
+
+/* ---- test hooks (dense K-dimension products used by the QP; exercised by tests/test_gemm_gpu.py) ------
+ * Y[R][C] = alpha * A[R][M] X[M][C] + beta * Y, row-major, device pointers. */
+int scp_gemm_f64(scp_ctx* ctx, int use_mfma, int R, int M, int C, double alpha, const double* A,
+                 const double* X, double beta, double* Y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCP_HIP_H */

@@ -1,0 +1,150 @@
+"""GPU parity of the joint QP (a3/a6/a9) through the C-ABI against oracle/qp_oracle.py.
+
+The QP boundary of the reference is OSQP ("parity unpinned", see oracle/qp_oracle.py): the HIP solver is
+compared (i) with the oracle's line-by-line statement of the same algorithm (admm_structured) at 1e-9 and
+(ii) with the independent explicit-matrix OSQP restatement run to 1e-9 accuracy, i.e. the unique minimiser."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import qp_oracle as qo
+from oracle import scp_oracle as so
+
+pytestmark = pytest.mark.gpu
+LIMITS = [-2.0, 2.0, -15.0, 15.0, -20.0, 20.0]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from path_planning import _hip
+
+    c = _hip.Context(0)
+    yield c
+    c.close()
+
+
+def ref_problem(n, seed, T=10.0, h=0.2, R=0.8):
+    from path_planning.scenarios.position_generator import generate_positions
+
+    p0, pf = generate_positions(n, R, seed=seed)
+    return so.make_problem(n, T, h, R, [0, 0, 20, 20], p0, pf)
+
+
+def make_qp(ctx, prob, **kw):
+    from path_planning import _hip
+
+    st = _hip.default_settings(**kw)
+    qp = _hip.QP(ctx, prob.N, prob.K, prob.D, prob.h, st)
+    space = np.concatenate([prob.pos_min, prob.pos_max])
+    qp.set_problem(LIMITS, space, ctx.tensor(prob.p0), ctx.tensor(prob.v0), ctx.tensor(prob.pf), ctx.tensor(prob.vf))
+    return qp
+
+
+def oracle_settings(**kw):
+    base = dict(cg_iters=5)
+    base.update(kw)
+    return qo.Settings(**base)
+
+
+@pytest.mark.parametrize("use_mfma", [1, 0])
+@pytest.mark.parametrize("n,seed,T,h", [(4, 1, 10.0, 0.5), (20, 20, 10.0, 0.2)])
+def test_qp0_matches_oracle(ctx, n, seed, T, h, use_mfma):
+    prob = ref_problem(n, seed, T, h)
+    for eps in (1e-3, 1e-8):
+        qp = make_qp(ctx, prob, eps_abs=eps, eps_rel=eps, use_mfma=use_mfma)
+        qp.reset(None)
+        info = qp.solve()
+        x = qp.solution().cpu().numpy()
+        xo, yo, io = qo.admm_structured(prob, st=oracle_settings(eps_abs=eps, eps_rel=eps))
+        assert info["status_val"] == 1 and io["status_val"] == 1
+        assert info["iter"] == io["iter"] and info["rho_updates"] == io["rho_updates"]
+        np.testing.assert_allclose(x, xo, rtol=0, atol=1e-9)
+        assert abs(info["rho"] - io["rho"]) <= 1e-5 * io["rho"]  # rho is a ratio of 1e-9-size residuals
+        # duals in the reference stacking order
+        yf, _ = qp.duals()
+        yo_flat = np.hstack([yo[k].ravel() for k in ("jerk", "acc", "vel", "pos")])
+        np.testing.assert_allclose(yf.cpu().numpy(), yo_flat, rtol=0, atol=1e-8)
+        qp.close()
+    # exact minimiser: explicit-matrix OSQP restatement at 1e-9
+    C, l, u = so.stack_fixed(prob)
+    r = qo.osqp_explicit(2 * sp.eye(prob.n, format="csc"), np.zeros(prob.n), C, l, u, eps_abs=1e-9, eps_rel=1e-9,
+                         max_iter=20000)
+    assert r["status_val"] == 1
+    np.testing.assert_allclose(x.ravel(), r["x"], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("n,seed,T,h,margin", [(4, 1, 10.0, 0.5, 0.5), (10, 7, 10.0, 0.2, 0.5), (4, 1, 10.0, 0.5, 1e9)])
+def test_collision_qp_matches_oracle(ctx, n, seed, T, h, margin):
+    """First SCP iteration's joint QP, working set fixed by `margin` (1e9 = every collision row)."""
+    from path_planning import _hip
+
+    prob = ref_problem(n, seed, T, h)
+    x0, _, _ = qo.admm_structured(prob, st=oracle_settings(eps_abs=1e-8, eps_rel=1e-8))
+    pos, _ = so.kinematics(prob, x0)
+    eta, l_col, dist = so.linearize_pairs(prob, pos)
+    W = np.nonzero(dist - prob.R < margin)[0]
+    for eps, max_iter in ((1e-3, 10000), (1e-6, 20000)):
+        st = oracle_settings(eps_abs=eps, eps_rel=eps, max_iter=max_iter, max_rounds=1)
+        xo, yo, io = qo.admm_structured(prob, eta, l_col, dist, x0=x0, st=st, rows0=W)
+        qp = make_qp(ctx, prob, eps_abs=eps, eps_rel=eps, max_iter=max_iter)
+        qp.reset(ctx.tensor(x0))
+        import torch
+
+        rows = torch.as_tensor(W, dtype=torch.int64, device=ctx.tdev)
+        qp.add_rows(rows, ctx.tensor(eta[W]), ctx.tensor(l_col[W]))
+        info = qp.solve()
+        x = qp.solution().cpu().numpy()
+        assert info["status_val"] == io["status_val"] == 1
+        assert info["iter"] == io["iter"], (info, io)
+        assert info["working_rows"] == W.size
+        np.testing.assert_allclose(x, xo, rtol=0, atol=1e-8)
+        _, yc = qp.duals()
+        np.testing.assert_allclose(yc.cpu().numpy(), yo["col"], rtol=0, atol=1e-7)
+        qp.close()
+    # against the exact minimiser of the same (working-set) QP, explicit matrices
+    C, lf, uf = so.stack_fixed(prob)
+    A = sp.vstack([C, so.collision_matrix_explicit(prob, eta)[W]], format="csc")
+    r = qo.osqp_explicit(2 * sp.eye(prob.n, format="csc"), np.zeros(prob.n), A, np.hstack([lf, l_col[W]]),
+                         np.hstack([uf, np.full(W.size, np.inf)]), x0=x0.ravel(), eps_abs=1e-9, eps_rel=1e-9,
+                         max_iter=100000)
+    assert r["status_val"] == 1
+    assert np.abs(x.ravel() - r["x"]).max() < 5e-4  # eps = 1e-6 ADMM point vs the exact minimiser
+
+
+def test_qp_3d_z0_metamorphic(ctx):
+    """D=3 with z == 0 everywhere reproduces the D=2 solution."""
+    prob2 = ref_problem(6, 3, 10.0, 0.5)
+    z = np.zeros((prob2.N, 1))
+    prob3 = so.make_problem(prob2.N, 10.0, 0.5, prob2.R, [0, 0, -5, 20, 20, 5], np.hstack([prob2.p0, z]),
+                            np.hstack([prob2.pf, z]))
+    xs = []
+    for prob in (prob2, prob3):
+        qp = make_qp(ctx, prob, eps_abs=1e-8, eps_rel=1e-8)
+        qp.reset(None)
+        assert qp.solve()["status_val"] == 1
+        xs.append(qp.solution().cpu().numpy())
+        qp.close()
+    np.testing.assert_allclose(xs[1][:, :, :2], xs[0], rtol=0, atol=1e-10)
+    assert np.abs(xs[1][:, :, 2]).max() < 1e-12
+
+
+def test_qp_errors(ctx):
+    from path_planning import _hip
+
+    prob = ref_problem(4, 1, 10.0, 0.5)
+    st = _hip.default_settings()
+    qp = _hip.QP(ctx, prob.N, prob.K, 2, prob.h, st, row_capacity=4)
+    with pytest.raises(_hip.HipError):  # reset before set_problem
+        qp.reset(None)
+    space = np.concatenate([prob.pos_min, prob.pos_max])
+    qp.set_problem(LIMITS, space, ctx.tensor(prob.p0), ctx.tensor(prob.v0), ctx.tensor(prob.pf), ctx.tensor(prob.vf))
+    qp.reset(None)
+    import torch
+
+    rows = torch.arange(5, dtype=torch.int64, device=ctx.tdev)
+    with pytest.raises(_hip.HipError) as e:  # capacity
+        qp.add_rows(rows, ctx.tensor(np.ones((5, 2))), ctx.tensor(np.zeros(5)))
+    assert e.value.code == _hip.SCP_ERR_CAPACITY
+    with pytest.raises(_hip.HipError):
+        _hip.QP(ctx, 4, 20, 4, 0.5)  # D = 4
+    qp.close()

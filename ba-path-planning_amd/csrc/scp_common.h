@@ -17,6 +17,8 @@ struct scp_ctx {
   double* d_scratch;      // 64 doubles
   double* h_scratch;      // pinned, 64 doubles
   hipEvent_t ev0, ev1;
+  hipEvent_t pair_ev0, pair_ev1;  // bracket the most recent pairwise kernel (scp_ctx_last_pair_ms)
+  bool pair_timed;
   double* tm_scratch;     // time-major copy of a trajectory array for the pairwise passes (grown on demand)
   size_t tm_bytes;
 };

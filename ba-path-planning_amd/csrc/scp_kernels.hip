@@ -20,7 +20,8 @@ extern "C" int scp_ctx_create(int device, void* hip_stream, scp_ctx** out) {
   ctx->stream = (hipStream_t)hip_stream;
   if (hipMalloc(&ctx->d_scratch, 64 * sizeof(double)) != hipSuccess ||
       hipHostMalloc(&ctx->h_scratch, 64 * sizeof(double)) != hipSuccess ||
-      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+      hipEventCreate(&ctx->pair_ev0) != hipSuccess || hipEventCreate(&ctx->pair_ev1) != hipSuccess) {
     delete ctx;
     return SCP_ERR_HIP;
   }
@@ -37,6 +38,8 @@ extern "C" void scp_ctx_destroy(scp_ctx* ctx) {
   (void)hipHostFree(ctx->h_scratch);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
+  (void)hipEventDestroy(ctx->pair_ev0);
+  (void)hipEventDestroy(ctx->pair_ev1);
   delete ctx;
 }
 
@@ -565,6 +568,7 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
   const bool use_lds = lds_bytes <= 64 * 1024;
   dim3 grid(scp_cdiv(nq + 1, PAIR_ROWS), K);
   dim3 block(PAIR_THREADS);
+  SCP_HIP_CHECK(ctx, hipEventRecord(ctx->pair_ev0, ctx->stream));
 #define SCP_LAUNCH_PAIR(DD, LDS)                                                                        \
   hipLaunchKernelGGL((pair_pass_kernel<DD, MODE, LDS>), grid, block, (LDS) ? lds_bytes : 0, ctx->stream, a)
   if (D == 2) {
@@ -576,6 +580,17 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
   }
 #undef SCP_LAUNCH_PAIR
   SCP_HIP_CHECK(ctx, hipGetLastError());
+  SCP_HIP_CHECK(ctx, hipEventRecord(ctx->pair_ev1, ctx->stream));
+  ctx->pair_timed = true;
+  return SCP_OK;
+}
+
+// Device time of the most recent pairwise kernel alone (HIP events on the ctx stream around that one launch).
+extern "C" int scp_ctx_last_pair_ms(scp_ctx* ctx, float* ms) {
+  if (!ctx || !ms) return SCP_ERR_INVALID;
+  if (!ctx->pair_timed) return scp_fail(ctx, SCP_ERR_STATE, "no pairwise pass has run yet");
+  SCP_HIP_CHECK(ctx, hipEventSynchronize(ctx->pair_ev1));
+  SCP_HIP_CHECK(ctx, hipEventElapsedTime(ms, ctx->pair_ev0, ctx->pair_ev1));
   return SCP_OK;
 }
 

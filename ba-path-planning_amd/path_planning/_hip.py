@@ -55,6 +55,7 @@ class QpInfo(C.Structure):
 
 EXPORTS = [
     "scp_abi_version", "scp_ctx_create", "scp_ctx_destroy", "scp_last_error", "scp_ctx_synchronize",
+    "scp_ctx_last_pair_ms",
     "scp_kinematics", "scp_fixed_bounds", "scp_linearize_pairs", "scp_check_avoidance",
     "scp_collision_violations", "scp_gather_rows", "scp_rel_step", "scp_qp_default_settings",
     "scp_qp_workspace_bytes", "scp_qp_create", "scp_qp_destroy", "scp_qp_update_settings", "scp_qp_set_problem",
@@ -89,6 +90,7 @@ def load_library():
     lib.scp_last_error.argtypes = [vp]
     lib.scp_last_error.restype = C.c_char_p
     lib.scp_ctx_synchronize.argtypes = [vp]
+    lib.scp_ctx_last_pair_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.scp_kinematics.argtypes = [vp, i32, i32, i32, f64, vp, vp, vp, vp, vp]
     lib.scp_fixed_bounds.argtypes = [vp, i32, i32, i32, f64, pd, pd, vp, vp, vp, vp, vp, vp]
     lib.scp_linearize_pairs.argtypes = [vp, i32, i32, i32, f64, f64, i64, i64, vp, vp, vp, vp, vp, f64, vp, i64, vp, vp]
@@ -190,6 +192,11 @@ class Context:
         u = raw.view(np.uint64)
         return float(raw[0]), int(u[1]), int(u[2]), float(raw[3])
 
+    def last_pair_ms(self):
+        ms = C.c_float()
+        self.check(self.lib.scp_ctx_last_pair_ms(self.h, C.byref(ms)))
+        return float(ms.value)
+
     # ---- stateless entry points --------------------------------------------------------------------
     def kinematics(self, N, K, D, h, acc, p0, v0, want_vel=True):
         pos = self.empty(N, K, D)
@@ -247,6 +254,7 @@ class PairPass:
         self.bitmap = torch.zeros(max((self.rows + 31) // 32, 1), dtype=torch.int32, device=ctx.tdev)
         self.sel_cap = int(sel_cap if sel_cap is not None else min(max(self.rows, 1), max(65536, 64 * N * K)))
         self.sel = torch.empty(self.sel_cap, dtype=torch.int64, device=ctx.tdev)
+        self.last_linearize_ms = self.last_violations_ms = 0.0
 
     def _grow(self, need):
         torch = _torch()
@@ -262,6 +270,7 @@ class PairPass:
                                               self.l.data_ptr(), margin, self.sel.data_ptr(), self.sel_cap,
                                               self.bitmap.data_ptr(), c.stats.data_ptr()))
             min_dist, first, n_sel, _ = c.read_stats()
+            self.last_linearize_ms = c.last_pair_ms() if self.nq > 0 else 0.0
             if n_sel <= self.sel_cap:
                 return self.sel[:n_sel].clone(), min_dist, first
             self._grow(n_sel)
@@ -277,6 +286,7 @@ class PairPass:
                                                    p0.data_ptr(), v0.data_ptr(), feas_tol, self.sel.data_ptr(),
                                                    self.sel_cap, self.bitmap.data_ptr(), c.stats.data_ptr()))
             _, _, n_sel, max_v = c.read_stats()
+            self.last_violations_ms = c.last_pair_ms() if self.nq > 0 else 0.0
             if n_sel <= self.sel_cap:
                 return self.sel[:n_sel].clone(), max_v
             self.bitmap.copy_(snapshot)

@@ -1,0 +1,104 @@
+"""Multi-GPU plumbing of the SCP hot path (one process per GPU, torch.distributed; backend "nccl" is RCCL).
+
+What shards: the O(N^2 K) pairwise passes.  Rank g owns the contiguous range of lexicographic pair indices
+[q_begin, q_end) at every time step -- balanced by construction because it is cut in PAIR space, not in
+agent space -- and the agents [i_begin, i_end) for the kinematics.  One exchange step per SCP iteration:
+``allgather_positions`` (the per-shard trajectories, so that every rank sees all neighbours) and, for the
+joint QP, ``allgather_rows`` of each rank's compact working rows.  Everything here works on CPU tensors with
+the gloo backend too (tests/test_sharding_cpu.py runs it with world_size 2).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class Shard:
+    """rank / world_size view of an N-agent problem; world_size == 1 needs no process group."""
+
+    def __init__(self, N, rank=0, world_size=1, group=None):
+        self.N, self.rank, self.world, self.group = int(N), int(rank), int(world_size), group
+        if self.world > 1 and not dist.is_initialized():
+            raise RuntimeError("world_size > 1 needs an initialised torch.distributed process group")
+        self.pairs = self.N * (self.N - 1) // 2
+
+    # ---- partitions ----------------------------------------------------------------------------
+    def pair_range(self, rank=None):
+        r = self.rank if rank is None else rank
+        return self.pairs * r // self.world, self.pairs * (r + 1) // self.world
+
+    def agent_range(self, rank=None):
+        r = self.rank if rank is None else rank
+        return self.N * r // self.world, self.N * (r + 1) // self.world
+
+    # ---- collectives ---------------------------------------------------------------------------
+    def allgather_positions(self, local):
+        """local: (n_local, K, D) trajectories of this rank's agents -> (N, K, D) on every rank."""
+        if self.world == 1:
+            return local
+        counts = [self.agent_range(r)[1] - self.agent_range(r)[0] for r in range(self.world)]
+        if len(set(counts)) == 1:
+            out = torch.empty((self.N,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+            return out
+        width = max(counts)
+        pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(parts, pad, group=self.group)
+        return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+
+    def allgather_rows(self, rows, w_eta, w_l):
+        """Concatenate every rank's compact rows (ids (n,), eta (n, D), l (n,)) in rank order."""
+        if self.world == 1:
+            return rows, w_eta, w_l
+        n = torch.tensor([rows.numel()], dtype=torch.int64, device=rows.device)
+        counts = [torch.zeros_like(n) for _ in range(self.world)]
+        dist.all_gather(counts, n, group=self.group)
+        counts = [int(c.item()) for c in counts]
+        width = max(max(counts), 1)
+        D = w_eta.shape[1] if w_eta.dim() == 2 else 1
+        # one padded message per rank: [row id as float64 bits | eta (D) | l]  -> a single collective
+        msg = torch.zeros(width, D + 2, dtype=torch.float64, device=rows.device)
+        k = rows.numel()
+        if k:
+            msg[:k, 0] = rows.view(torch.float64) if rows.dtype == torch.int64 else rows.to(torch.int64).view(torch.float64)
+            msg[:k, 1 : D + 1] = w_eta.reshape(k, D)
+            msg[:k, D + 1] = w_l
+        parts = [torch.empty_like(msg) for _ in range(self.world)]
+        dist.all_gather(parts, msg, group=self.group)
+        allmsg = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+        return allmsg[:, 0].contiguous().view(torch.int64), allmsg[:, 1 : D + 1].contiguous(), allmsg[:, D + 1].contiguous()
+
+    def broadcast(self, tensor, src=0):
+        if self.world > 1:
+            dist.broadcast(tensor, src=src, group=self.group)
+        return tensor
+
+    def all_min(self, value: float) -> float:
+        if self.world == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=self._dev())
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return float(t.item())
+
+    def all_max(self, value: float) -> float:
+        if self.world == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=self._dev())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def all_min_int(self, value: int) -> int:
+        """min over ranks of a non-negative integer < 2^63 (first-violation row ids; UINT64_MAX -> 2^63-1)."""
+        if self.world == 1:
+            return value
+        v = min(int(value), (1 << 63) - 1)
+        t = torch.tensor([v], dtype=torch.int64, device=self._dev())
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return int(t.item())
+
+    def _dev(self):
+        if dist.get_backend(self.group) == "nccl":
+            return torch.device("cuda", torch.cuda.current_device())
+        return torch.device("cpu")

@@ -1,0 +1,229 @@
+"""``compute-trajectories-batch``: timing benchmark over robot counts and trials -> JSON + CSV
+(entry point of the reference, /root/reference/src/path_planning/cli/compute_trajectories_batch.py:70-177,
+pyproject.toml:54).
+
+The CONFIG dict, the per-run record {N, status, time_sec, error, K, T, h, trial_index}, the summary statistics
+and the JSON/CSV schema ("schema_version": "1.0", CSV field order) are the reference's, so ``scp-boxplot``
+consumes the files unchanged.  Additions: a per-trial ``seed`` (the reference leaves it as a TODO, :40, :65), the
+scenario family, and scenario-parallel execution: with WORLD_SIZE > 1 (torchrun, one process per GPU) the
+(N, trial) jobs are dealt round-robin to the ranks, no collective on the data path, and rank 0 merges the
+records -- config 5 of BASELINE.json ("512 scenarios x 128 agents, scenario-parallel across 8 GPUs")."""
+import argparse
+import csv
+import json
+import os
+import time
+from datetime import datetime
+from pathlib import Path
+
+import numpy as np
+
+from ..scenarios.position_generator import generate_grid_swap, generate_positions
+from ..solvers.scp import SCP
+
+# ---------------------------- Config (reference defaults, compute_trajectories_batch.py:14-24) -------------
+CONFIG = {
+    "Ns": [18, 20],
+    "trials_per_N": 10,
+    "time_horizon": 10.0,
+    "time_step": 0.2,
+    "min_distance": 0.8,
+    "space_dims": [0, 0, 20, 20],
+    "max_iterations": 15,
+    "rng_seed": None,
+    "results_dir": "data/trial_xxx",
+    # additions
+    "scenario": "reference",  # or "grid-swap" (needed for N >= 60)
+    "dim": 2,
+}
+
+
+def trial_seed(cfg, N, trial):
+    """seed = rng_seed + 1000*N + trial (the reference's formula at :108), None when rng_seed is None."""
+    if cfg["rng_seed"] is None:
+        return None
+    return int(cfg["rng_seed"]) + 1000 * N + trial
+
+
+def run_single_trial(N, cfg, rng=None, seed=None, device=None):
+    """One SCP solve for N vehicles -> result record (compute_trajectories_batch.py:28-67)."""
+    if cfg.get("scenario", "reference") == "grid-swap":
+        init_pos, final_pos, space = generate_grid_swap(N, seed=seed or 0, dim=cfg.get("dim", 2))
+    else:
+        init_pos, final_pos = generate_positions(N, cfg["min_distance"], seed=seed)
+        space = cfg["space_dims"]
+    solver = None
+    t0 = time.perf_counter()
+    status = "success"
+    err_msg = None
+    iters = None
+    try:
+        solver = SCP(
+            n_vehicles=N,
+            time_horizon=cfg["time_horizon"],
+            time_step=cfg["time_step"],
+            min_distance=cfg["min_distance"],
+            space_dims=space,
+            dim=cfg.get("dim", 2),
+            device=device,
+            verbose=cfg.get("verbose", False),
+        )
+        solver.set_initial_states(init_pos)
+        solver.set_final_states(final_pos)
+        t0 = time.perf_counter()
+        _ = solver.generate_trajectories(max_iterations=cfg["max_iterations"])
+        iters = solver.last_info.get("n_iterations")
+    except Exception as e:
+        status = "error"
+        err_msg = str(e)
+    t1 = time.perf_counter()
+    return {
+        "N": N,
+        "status": status,
+        "time_sec": t1 - t0,
+        "error": err_msg,
+        "K": getattr(solver, "K", None),
+        "T": getattr(solver, "T", cfg["time_horizon"]),
+        "h": getattr(solver, "h", cfg["time_step"]),
+        "seed": seed,
+        "scp_iterations": iters,
+    }
+
+
+def summarise(runs, Ns):
+    """Per-N statistics over the successful runs (compute_trajectories_batch.py:122-150)."""
+    summary = {}
+    for N in Ns:
+        times = [r["time_sec"] for r in runs if r["N"] == N and r["status"] == "success"]
+        errors = sum(1 for r in runs if r["N"] == N and r["status"] != "success")
+        if times:
+            summary[str(N)] = {
+                "count": len(times),
+                "errors": errors,
+                "min": float(np.min(times)),
+                "max": float(np.max(times)),
+                "mean": float(np.mean(times)),
+                "median": float(np.median(times)),
+                "p25": float(np.percentile(times, 25)),
+                "p75": float(np.percentile(times, 75)),
+                "std": float(np.std(times, ddof=1)) if len(times) > 1 else 0.0,
+            }
+        else:
+            summary[str(N)] = {k: None for k in ("min", "max", "mean", "median", "p25", "p75", "std")}
+            summary[str(N)].update(count=0, errors=errors)
+    return summary
+
+
+CSV_FIELDS = ["N", "trial_index", "status", "time_sec", "K", "T", "h", "error"]  # reference order (:158)
+
+
+def write_results(all_results, json_path, csv_path):
+    with open(json_path, "w", encoding="utf-8") as f:
+        json.dump(all_results, f, indent=2)
+    with open(csv_path, "w", newline="", encoding="utf-8") as f:
+        w = csv.DictWriter(f, fieldnames=CSV_FIELDS)
+        w.writeheader()
+        for r in all_results["runs"]:
+            w.writerow({k: r.get(k, None) for k in CSV_FIELDS})
+
+
+def jobs_for_rank(cfg, rank, world):
+    jobs = [(N, t) for N in cfg["Ns"] for t in range(cfg["trials_per_N"])]
+    return jobs[rank::world]
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog="compute-trajectories-batch", description=__doc__.split("\n\n")[0])
+    p.add_argument("--Ns", type=int, nargs="+", default=None)
+    p.add_argument("--trials", type=int, default=None)
+    p.add_argument("--scenario", choices=["reference", "grid-swap"], default=None)
+    p.add_argument("--dim", type=int, choices=[2, 3], default=None)
+    p.add_argument("--seed", type=int, default=None)
+    p.add_argument("--results-dir", default=None)
+    p.add_argument("--max-iterations", type=int, default=None)
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args([] if argv is None else argv)
+    cfg = CONFIG.copy()
+    for key, val in (("Ns", args.Ns), ("trials_per_N", args.trials), ("scenario", args.scenario), ("dim", args.dim),
+                     ("rng_seed", args.seed), ("results_dir", args.results_dir),
+                     ("max_iterations", args.max_iterations)):
+        if val is not None:
+            cfg[key] = val
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            dist.init_process_group("gloo")  # control plane only: gathers the result records
+
+    Path(cfg["results_dir"]).mkdir(parents=True, exist_ok=True)
+    stamp = datetime.now().strftime("%Y%m%d_%H%M%S")
+    json_path = Path(cfg["results_dir"]) / f"scp_benchmark_{stamp}.json"
+    csv_path = Path(cfg["results_dir"]) / f"scp_benchmark_{stamp}.csv"
+
+    if cfg["rng_seed"] is not None:
+        np.random.seed(cfg["rng_seed"])
+
+    if rank == 0:
+        print("------ WOW SCP Benchmark ------")
+        print(f"Robot counts: {cfg['Ns']}, Trials per N: {cfg['trials_per_N']}")
+        print(f"T={cfg['time_horizon']}s, h={cfg['time_step']}s, R={cfg['min_distance']}m, space={cfg['space_dims']}")
+        print(f"Max SCP iterations: {cfg['max_iterations']}")
+        print()
+
+    runs = []
+    for N, trial in jobs_for_rank(cfg, rank, world):
+        seed = trial_seed(cfg, N, trial)
+        if seed is not None:
+            np.random.seed(seed)
+        res = run_single_trial(N, cfg, rng=np.random, seed=seed, device=local_rank)
+        res["trial_index"] = trial
+        runs.append(res)
+        status_str = "OK" if res["status"] == "success" else f"ERR ({res['error']})"
+        print(f"  [rank {rank}] N={N} trial {trial+1:02d}/{cfg['trials_per_N']}  time = {res['time_sec']:.3f}s  [{status_str}]")
+
+    if world > 1:
+        import torch.distributed as dist
+
+        gathered = [None] * world
+        dist.all_gather_object(gathered, runs)
+        runs = [r for part in gathered for r in part]
+    if rank != 0:
+        return None
+    runs.sort(key=lambda r: (cfg["Ns"].index(r["N"]), r["trial_index"]))
+
+    all_results = {
+        "meta": {
+            "timestamp": stamp,
+            "description": "SCP timing benchmark for multiple N; each entry is a full solve wall time.",
+            "config": cfg,
+            "schema_version": "1.0",
+        },
+        "runs": runs,
+        "summary": summarise(runs, cfg["Ns"]),
+    }
+    write_results(all_results, json_path, csv_path)
+    print(f"Saved JSON: {json_path}")
+    print(f"Saved CSV:  {csv_path}")
+    print("\nSummary (success-only times):")
+    for N in cfg["Ns"]:
+        s = all_results["summary"][str(N)]
+        print(f"  N={N}: count={s['count']}, errors={s['errors']}, "
+              f"mean={s['mean']}, median={s['median']}, p25={s['p25']}, p75={s['p75']}")
+    return all_results
+
+
+def console_main():
+    import sys
+
+    main(sys.argv[1:])
+
+
+if __name__ == "__main__":
+    console_main()

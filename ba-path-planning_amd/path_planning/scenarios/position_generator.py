@@ -77,12 +77,36 @@ def generate_positions(n_vehicles, min_distance=0.4, max_attempts=1000, seed=Non
     return initial, final
 
 
-def generate_grid_swap(n_agents, seed=0, pitch=2.0, jitter=0.2, block=4, dim=2, layer_gap=2.0):
-    """Synthetic scenario for large N.  Returns (initial (N,dim), final (N,dim), space_dims).
+def straight_line_min_distance(init, goal, idx_a=None, idx_b=None):
+    """Closest approach of the straight-line, equal-time-profile motions p_i(s) = a_i + s (b_i - a_i),
+    s in [0, 1]: the relative position is linear in s, so the minimum is a point-segment distance.
+    Returns the (len(idx_a), len(idx_b)) matrix (all pairs by default; the diagonal is +inf)."""
+    init = np.asarray(init, float)
+    goal = np.asarray(goal, float)
+    ia = np.arange(len(init)) if idx_a is None else np.asarray(idx_a)
+    ib = np.arange(len(init)) if idx_b is None else np.asarray(idx_b)
+    r0 = init[ia][:, None, :] - init[ib][None, :, :]
+    dr = (goal[ia][:, None, :] - goal[ib][None, :, :]) - r0
+    den = np.sum(dr * dr, axis=2)
+    s = np.clip(-np.sum(r0 * dr, axis=2) / np.where(den > 0, den, 1.0), 0.0, 1.0)
+    d = np.linalg.norm(r0 + s[..., None] * dr, axis=2)
+    d[ia[:, None] == ib[None, :]] = np.inf
+    return d
+
+
+def generate_grid_swap(n_agents, seed=0, pitch=2.0, jitter=0.2, block=4, dim=2, layer_gap=2.0, min_sep=0.3,
+                       max_tries=8192):
+    """Synthetic scenario for large N (SURVEY.md section 8d).  Returns (initial (N,dim), final (N,dim), space_dims).
 
     dim=2: agents on a ceil(sqrt(N))^2 grid; dim=3: ceil(cbrt(N)) layers ``layer_gap`` apart, each a
-    2-D grid.  Goals are the starts under a seeded permutation inside ``block`` x ``block`` cells
-    (within a layer), so the displacement is at most (block-1)*pitch*sqrt(2) + 2*jitter*sqrt(2).
+    2-D grid.  Goals are the grid cells under a seeded permutation inside ``block`` x ``block`` cells
+    (within a layer) with their own jitter, so the displacement is at most
+    (block-1)*pitch*sqrt(2) + 2*jitter*sqrt(2) -- feasible for |v| <= 2 m/s, T = 10 s.
+
+    A block's permutation is re-drawn (at most ``max_tries`` times) until the straight-line motions of its agents
+    never come closer than ``min_sep``: an exact or near head-on swap (closest approach ~ 0) makes the FIRST
+    linearised QP of the SCP infeasible -- the constraint normals flip sign within one time step -- for the
+    reference algorithm as much as for this one.  A final pass re-draws blocks that conflict across block borders.
     space_dims = [min_0.., max_0..] with a 2 m rim."""
     rng = np.random.default_rng(seed)
     if dim == 2:
@@ -95,6 +119,33 @@ def generate_grid_swap(n_agents, seed=0, pitch=2.0, jitter=0.2, block=4, dim=2, 
     side = math.ceil(math.sqrt(per))
     gx, gy = np.meshgrid(np.arange(side), np.arange(side), indexing="ij")
     cells = np.stack([gx.ravel(), gy.ravel()], axis=1)
+
+    def draw_block(cell, xy, idx):
+        """goal positions for the agents idx of one block: candidates are drawn 256 at a time"""
+        m = idx.size
+        if m == 1:
+            return cell[idx] * pitch + rng.uniform(-jitter, jitter, size=(1, 2))
+        best, best_d = None, -1.0
+        off = ~np.eye(m, dtype=bool)
+        for _ in range(max(1, max_tries // 256)):
+            T = 256
+            perm = np.argsort(rng.random((T, m)), axis=1)
+            g = cell[idx[perm]] * pitch + rng.uniform(-jitter, jitter, size=(T, m, 2))
+            a = xy[idx]
+            r0 = a[None, :, None, :] - a[None, None, :, :]
+            dr = (g[:, :, None, :] - g[:, None, :, :]) - r0
+            den = np.sum(dr * dr, axis=3)
+            sp = np.clip(-np.sum(r0 * dr, axis=3) / np.where(den > 0, den, 1.0), 0.0, 1.0)
+            d = np.linalg.norm(r0 + sp[..., None] * dr, axis=3)
+            dmin = np.where(off[None], d, np.inf).reshape(T, -1).min(axis=1)
+            ok = np.nonzero(dmin >= min_sep)[0]
+            pick = int(ok[0]) if ok.size else int(np.argmax(dmin))
+            if dmin[pick] > best_d:
+                best, best_d = g[pick], float(dmin[pick])
+            if ok.size:
+                break
+        return best
+
     init = []
     goal = []
     remaining = n_agents
@@ -103,13 +154,29 @@ def generate_grid_swap(n_agents, seed=0, pitch=2.0, jitter=0.2, block=4, dim=2, 
         remaining -= cnt
         cell = cells[:cnt]
         xy = cell * pitch + rng.uniform(-jitter, jitter, size=(cnt, 2))
-        # permute inside block x block cells
         key = (cell[:, 0] // block) * (side // block + 1) + (cell[:, 1] // block)
-        tgt = np.arange(cnt)
-        for kk in np.unique(key):
-            idx = np.nonzero(key == kk)[0]
-            tgt[idx] = idx[rng.permutation(idx.size)]
-        gxy = xy[tgt]
+        gxy = np.empty_like(xy)
+        groups = [np.nonzero(key == kk)[0] for kk in np.unique(key)]
+        for idx in groups:
+            gxy[idx] = draw_block(cell, xy, idx)
+        # conflicts across block borders: re-draw one of the two blocks, a few sweeps
+        owner = np.empty(cnt, dtype=int)
+        for b, idx in enumerate(groups):
+            owner[idx] = b
+        for _ in range(20):
+            bad = set()
+            step = 512
+            for s0 in range(0, cnt, step):
+                ia = np.arange(s0, min(cnt, s0 + step))
+                d = straight_line_min_distance(xy, gxy, ia, np.arange(cnt))
+                rr, cc = np.nonzero(d < min_sep)
+                for r_, c_ in zip(ia[rr], cc):
+                    if owner[r_] != owner[c_]:
+                        bad.add(int(max(owner[r_], owner[c_])))
+            if not bad:
+                break
+            for b in bad:
+                gxy[groups[b]] = draw_block(cell, xy, groups[b])
         if dim == 3:
             z = np.full((cnt, 1), L * layer_gap)
             xy = np.hstack([xy, z])

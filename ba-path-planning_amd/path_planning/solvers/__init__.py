@@ -1,0 +1,3 @@
+from .scp import SCP
+
+__all__ = ["SCP"]

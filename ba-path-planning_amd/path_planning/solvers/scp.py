@@ -1,0 +1,427 @@
+"""SCP trajectory planner -- MI355X-native drop-in for the reference's ``path_planning.solvers.scp.SCP``.
+
+Same constructor, attributes, methods, stdout lines and error behaviour as
+/root/reference/src/path_planning/solvers/scp.py (class SCP, :31-616); every method below cites the lines it
+replaces.  The numerical work runs in hand-written HIP kernels behind the C-ABI of include/scp_hip.h
+(libscp_hip.so, bound with ctypes in path_planning/_hip.py); PyTorch-ROCm tensors are device buffers only.
+There is no CPU fallback: constructing the solver without a GPU or without the built library raises.
+
+Differences to the reference that a caller can observe (INTEGRATION.md has the full list):
+  * the QP solver is this repo's ADMM (OSQP's algorithm, matrix-free) instead of the `osqp` package, so
+    iterates agree with the reference only up to OSQP's own tolerance (eps_abs = eps_rel = 1e-3);
+  * ``_add_collision_constraints`` returns the compact form (eta, l) of the constraint rows instead of a
+    2.6e9-non-zero CSC matrix; ``C_jerk/C_acc/C_vel/C_pos`` are not materialised (they stay None);
+  * new keyword-only arguments: ``dim`` (2 or 3), ``device``, ``qp_settings``, ``working_set_margin``,
+    ``feasibility_tol``, ``verbose``, ``rank``/``world_size``/``group`` (agent-sharded multi-GPU).
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from .. import _hip
+from .._sharding import Shard
+
+
+class SCP:
+    def __init__(
+        self,
+        n_vehicles=5,
+        time_horizon=3.0,
+        time_step=0.1,
+        min_distance=0.1,
+        space_dims=None,
+        *,
+        dim=2,
+        device=None,
+        qp_settings=None,
+        working_set_margin=0.5,
+        feasibility_tol=1e-6,
+        max_rounds=20,
+        verbose=True,
+        rank=0,
+        world_size=1,
+        group=None,
+    ):
+        # --- reference attributes (scp.py:40-91) ---
+        self.N = n_vehicles
+        self.T = time_horizon
+        self.h = time_step
+        self.K = int(self.T / self.h)  # scp.py:43
+        self.R = min_distance
+        self.D = int(dim)
+        if self.D not in (2, 3):
+            raise ValueError("dim must be 2 or 3")
+        if space_dims is None:
+            space_dims = [0, 0, 20, 20] if self.D == 2 else [0, 0, 0, 20, 20, 20]
+        self.space_dims = space_dims
+        if len(space_dims) != 2 * self.D:
+            raise ValueError(f"space_dims needs {2 * self.D} entries [min..., max...]")
+        self.convergence_tolerance = 1.5e-2
+        self.trajectories = None
+        self.initial_positions = None
+        self.initial_velocities = None
+        self.final_positions = None
+        self.final_velocities = None
+        self.pos_min = np.array(space_dims[: self.D])
+        self.pos_max = np.array(space_dims[self.D:])
+        self.vel_min = -2
+        self.vel_max = 2
+        self.acc_min = -15.0
+        self.acc_max = 15.0
+        self.jerk_min = -20
+        self.jerk_max = 20
+        self.C_jerk = self.C_acc = self.C_vel = self.C_pos = None  # never materialised on this path
+        self.l_jerk, self.u_jerk = [], []
+        self.l_acc, self.u_acc = [], []
+        self.l_vel, self.u_vel = [], []
+        self.l_pos, self.u_pos = [], []
+
+        # --- MI355X path ---
+        self.verbose = verbose
+        self.working_set_margin = float(working_set_margin)
+        self.feasibility_tol = float(feasibility_tol)
+        self.max_rounds = int(max_rounds)
+        self._qp_overrides = dict(qp_settings or {})
+        self.shard = Shard(self.N, rank, world_size, group)
+        if device is None:
+            import torch
+
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        self._ctx = _hip.Context(device)  # raises without a GPU / without libscp_hip.so
+        self._qp = None
+        self._pairs = None
+        self._dev = {}
+        self.last_info = {}
+
+        self._print("---=== SCP Problem initialized ===---")
+        self._print(f"Number of timesteps: {self.K}")
+        self._print(f"Timestep: {self.h}")
+        self._print(f"Minimum distance between vehicles: {self.R}")
+        self._print(f"Space dimensions: {self.space_dims}")
+
+    def _print(self, *a):
+        if self.verbose and self.shard.rank == 0:
+            print(*a)
+
+    # ------------------------------------------------------------------------------------------------
+    # a0: states (scp.py:99-129)
+    # ------------------------------------------------------------------------------------------------
+    def set_initial_states(self, positions, velocities=None):
+        """Set initial states for all vehicles in flat format (scp.py:99-113)."""
+        if velocities is None:
+            velocities = np.zeros((self.N, self.D))
+        self.initial_positions = np.asarray(positions, dtype=float).flatten()
+        self.initial_velocities = np.asarray(velocities, dtype=float).flatten()
+        assert len(self.initial_positions) == len(self.initial_velocities) == self.D * self.N, (
+            f"Initial states mismatch"
+            f"positions={len(self.initial_positions)}, "
+            f"velocities={len(self.initial_velocities)}, "
+            f"expected={self.D * self.N}"
+        )
+        self._dev.pop("p0", None)
+
+    def set_final_states(self, positions, velocities=None):
+        """Set final states for all vehicles in flat format (scp.py:115-129)."""
+        if velocities is None:
+            velocities = np.zeros((self.N, self.D))
+        self.final_positions = np.asarray(positions, dtype=float).flatten()
+        self.final_velocities = np.asarray(velocities, dtype=float).flatten()
+        assert len(self.final_positions) == len(self.final_velocities) == self.D * self.N, (
+            f"Final states mismatch"
+            f"positions={len(self.final_positions)}, "
+            f"velocities={len(self.final_velocities)}, "
+            f"expected={self.D * self.N}"
+        )
+        self._dev.pop("p0", None)
+
+    # ------------------------------------------------------------------------------------------------
+    # device-side setup
+    # ------------------------------------------------------------------------------------------------
+    def _limits(self):
+        return [self.vel_min, self.vel_max, self.acc_min, self.acc_max, self.jerk_min, self.jerk_max]
+
+    def _space(self):
+        return np.concatenate([np.asarray(self.pos_min, float), np.asarray(self.pos_max, float)])
+
+    def _states(self):
+        if "p0" not in self._dev:
+            c, sh = self._ctx, (self.N, self.D)
+            self._dev["p0"] = c.tensor(self.initial_positions.reshape(sh))
+            self._dev["v0"] = c.tensor(self.initial_velocities.reshape(sh))
+            self._dev["pf"] = c.tensor(self.final_positions.reshape(sh))
+            self._dev["vf"] = c.tensor(self.final_velocities.reshape(sh))
+        d = self._dev
+        return d["p0"], d["v0"], d["pf"], d["vf"]
+
+    def _ensure_qp(self):
+        if self._qp is None:
+            known = {k for k, _ in _hip.QpSettings._fields_}
+            st = _hip.default_settings(**{k: v for k, v in self._qp_overrides.items() if k in known})
+            self._qp = _hip.QP(self._ctx, self.N, self.K, self.D, self.h, st)
+        return self._qp
+
+    def _ensure_pairs(self):
+        if self._pairs is None:
+            q0, q1 = self.shard.pair_range()
+            self._pairs = _hip.PairPass(self._ctx, self.N, self.K, self.D, self.R, self.h, q0, q1)
+        return self._pairs
+
+    def _grow_qp(self, need):
+        """Working set outgrew the QP's row capacity: rebuild the solver with room for `need` rows."""
+        old = self._qp
+        cap = int(min(self.K * self.shard.pairs, max(need, 2 * old.row_capacity)))
+        st = old.settings
+        old.close()
+        self._qp = _hip.QP(self._ctx, self.N, self.K, self.D, self.h, st, row_capacity=cap)
+        p0, v0, pf, vf = self._states()
+        self._qp.set_problem(self._limits(), self._space(), p0, v0, pf, vf)
+        return self._qp
+
+    # ------------------------------------------------------------------------------------------------
+    # a1: SCP loop (scp.py:131-180)
+    # ------------------------------------------------------------------------------------------------
+    def generate_trajectories(self, max_iterations=15):
+        """Main method to generate collision-free trajectories using SCP (scp.py:131-180)."""
+        is_feasible = False
+        start_time = time.time()
+
+        self._precompute_constraint_matrices()
+        acc = self._solve_initial_trajectory()
+        init_guess_positions, _ = self._kinematics(acc, want_vel=False)
+        is_feasible = self._fast_check_avoidance_constraints(init_guess_positions)
+
+        iteration = 0
+        converged = False
+        self.last_info = {"iterations": [], "qp0": dict(self._last_qp_info)}
+        # `is_feasible` is evaluated once and never refreshed inside the loop (scp.py:144, :152)
+        while iteration < max_iterations and not converged and not is_feasible:
+            self._print(f"SCP Iteration {iteration+1}")
+            new_acc = self._solve_with_avoidance_constraints(acc)
+            _, _, rel_step_norm = self._ctx.rel_step(new_acc, acc)  # scp.py:157-159 (no zero guard)
+            self._print(rel_step_norm)
+            self.last_info["iterations"].append(dict(self._last_qp_info, rel_step=rel_step_norm))
+            if rel_step_norm <= self.convergence_tolerance:
+                converged = True
+                self._print(f"Converged after {iteration+1} iterations.")
+            acc = new_acc
+            iteration += 1
+
+        positions, velocities = self._kinematics(acc)
+        self.trajectories = {
+            "positions": positions.cpu().numpy(),  # Shape (N, K, D)
+            "velocities": velocities.cpu().numpy(),
+            "accelerations": acc.cpu().numpy(),
+        }
+        self.last_info.update(converged=converged, initially_feasible=bool(is_feasible), n_iterations=iteration)
+        end_time = time.time()
+        self._print(f"Trajectory generation completed in {end_time - start_time:.3f} seconds")
+        return self.trajectories
+
+    # ------------------------------------------------------------------------------------------------
+    # a2: fixed rows (scp.py:182-321) -- bounds only; the matrices are the shared K-column blocks
+    # ------------------------------------------------------------------------------------------------
+    def _precompute_constraint_matrices(self):
+        N, K, D = self.N, self.K, self.D
+        p0, v0, pf, vf = self._states()
+        lo, hi = self._ctx.fixed_bounds(N, K, D, self.h, self._limits(), self._space(), p0, v0, pf, vf)
+        lo, hi = lo.cpu().numpy(), hi.cpu().numpy()
+        nj, na = N * (K - 1) * D, N * K * D
+        self.l_jerk, self.u_jerk = lo[:nj], hi[:nj]
+        self.l_acc, self.u_acc = lo[nj:nj + na], hi[nj:nj + na]
+        self.l_vel, self.u_vel = lo[nj + na:nj + 2 * na], hi[nj + na:nj + 2 * na]
+        self.l_pos, self.u_pos = lo[nj + 2 * na:], hi[nj + 2 * na:]
+        # size checks of the reference (scp.py:265-299)
+        assert self.l_acc.shape == self.u_acc.shape == (D * N * K,)
+        assert self.l_jerk.shape == self.u_jerk.shape == (D * N * (K - 1),)
+        assert self.l_vel.shape == self.u_vel.shape == (D * N * K,)
+        assert self.l_pos.shape == self.u_pos.shape == (D * N * K,)
+        self._ensure_qp().set_problem(self._limits(), self._space(), p0, v0, pf, vf)
+
+    # ------------------------------------------------------------------------------------------------
+    # a3: QP#0 (scp.py:323-369)
+    # ------------------------------------------------------------------------------------------------
+    def _solve_initial_trajectory(self):
+        """Solve initial trajectory without avoidance constraints.  Returns a device tensor (N, K, D)."""
+        qp = self._ensure_qp()
+        qp.update_settings(max_iter=int(self._qp_overrides.get("max_iter0", self._qp_overrides.get("max_iter", 4000))))
+        qp.reset(None)
+        info = qp.solve()
+        self._last_qp_info = dict(info, rounds=1, added=[])
+        if info["status_val"] not in (1, 2):  # Solved / Solved Inaccurate (scp.py:363-365)
+            self._print("not feasible")
+            raise RuntimeError(f"OSQP failed: {info['status']}")
+        x = qp.solution()
+        self.shard.broadcast(x)
+        return x
+
+    # ------------------------------------------------------------------------------------------------
+    # a4 / a7: kinematics (scp.py:371-397, :559-595)
+    # ------------------------------------------------------------------------------------------------
+    def _kinematics(self, acc, want_vel=True):
+        """Agent-sharded kinematics + allgather of the per-shard trajectories (device tensors)."""
+        p0, v0, _, _ = self._states()
+        i0, i1 = self.shard.agent_range()
+        n = i1 - i0
+        if self.shard.world == 1:
+            return self._ctx.kinematics(self.N, self.K, self.D, self.h, acc, p0, v0, want_vel)
+        pos, vel = self._ctx.kinematics(n, self.K, self.D, self.h, acc[i0:i1].contiguous(), p0[i0:i1].contiguous(),
+                                        v0[i0:i1].contiguous(), want_vel)
+        pos = self.shard.allgather_positions(pos)
+        vel = self.shard.allgather_positions(vel) if want_vel else None
+        return pos, vel
+
+    def _to_device_acc(self, accelerations):
+        import torch
+
+        if isinstance(accelerations, torch.Tensor):
+            return accelerations.reshape(self.N, self.K, self.D).to(self._ctx.tdev, torch.float64).contiguous()
+        return self._ctx.tensor(np.asarray(accelerations, dtype=float).reshape(self.N, self.K, self.D))
+
+    def _compute_positions_velocities(self, accelerations):
+        """positions, velocities (N, K, D) numpy arrays from accelerations (scp.py:371-397)."""
+        pos, vel = self._kinematics(self._to_device_acc(accelerations))
+        return pos.cpu().numpy(), vel.cpu().numpy()
+
+    def _accelerations_to_positions_velocities(self, accelerations_flat):
+        """Same recurrences on the flat vector (scp.py:559-595); bitwise equal to the method above."""
+        return self._compute_positions_velocities(accelerations_flat)
+
+    # ------------------------------------------------------------------------------------------------
+    # a5: pairwise linearisation (scp.py:453-557)
+    # ------------------------------------------------------------------------------------------------
+    def _add_collision_constraints(self, previous_solution):
+        """Compact form of A_collision: returns (eta (rows, D), l_collision (rows,), u_collision (rows,)) as numpy
+        arrays for THIS rank's pair range, rows in the reference's k-major / i / j>i order.  Row r of the
+        reference's matrix is eta_r[d] h^2 (k-m-.5) on a_i[m] and the negative on a_j[m], m < k."""
+        acc = self._to_device_acc(previous_solution)
+        pos, _ = self._kinematics(acc, want_vel=False)
+        p0, v0, _, _ = self._states()
+        pp = self._ensure_pairs()
+        pp.linearize(pos, p0, v0, self.working_set_margin)
+        l = pp.l_rows().cpu().numpy()
+        return pp.eta_rows().cpu().numpy(), l, np.full(l.shape, np.inf)
+
+    # ------------------------------------------------------------------------------------------------
+    # a6: joint QP with collision rows (scp.py:399-451)
+    # ------------------------------------------------------------------------------------------------
+    def _solve_with_avoidance_constraints(self, accelerations_flat):
+        """Solve with collision avoidance constraints.  Takes / returns a device tensor (N, K, D).
+
+        The joint QP over ALL collision rows is solved by exact constraint generation: ADMM runs on the fixed rows
+        and a working set (rows with dist - R < working_set_margin at the linearisation point); a full pairwise
+        pass then checks every row at the solution and violated rows join the working set until none is left."""
+        acc = self._to_device_acc(accelerations_flat)
+        p0, v0, _, _ = self._states()
+        pp = self._ensure_pairs()
+        qp = self._ensure_qp()
+        max_iter = int(self._qp_overrides.get("max_iter", 10000))  # scp.py:442
+
+        prev_pos, _ = self._kinematics(acc, want_vel=False)
+        rows, _, _ = pp.linearize(prev_pos, p0, v0, self.working_set_margin)
+        w_eta, w_l = pp.gather(rows)
+        rows, w_eta, w_l = self.shard.allgather_rows(rows, w_eta, w_l)
+
+        all_rows, all_eta, all_l = [rows], [w_eta], [w_l]
+        qp.reset(acc)
+        try:
+            qp.add_rows(rows, w_eta, w_l)
+        except _hip.HipError as e:
+            if e.code != _hip.SCP_ERR_CAPACITY:
+                raise
+            qp = self._grow_qp(int(rows.numel()))
+            qp.reset(acc)
+            qp.add_rows(rows, w_eta, w_l)
+
+        used = 0
+        added = []
+        info = None
+        x = acc
+        total = {"iter": 0, "cg_iters_total": 0, "rho_updates": 0, "solve_ms": 0.0}
+        for rnd in range(self.max_rounds):
+            qp.update_settings(max_iter=max(max_iter - used, 1))
+            info = qp.solve()
+            used += info["iter"]
+            for k in total:
+                total[k] += info[k]
+            x = qp.solution()
+            self.shard.broadcast(x)
+            pos_new, _ = self._kinematics(x, want_vel=False)
+            new_rows, max_v = pp.violations(pos_new, p0, v0, self.feasibility_tol)
+            n_eta, n_l = pp.gather(new_rows)
+            new_rows, n_eta, n_l = self.shard.allgather_rows(new_rows, n_eta, n_l)
+            added.append(int(new_rows.numel()))
+            if new_rows.numel() == 0 or used >= max_iter:
+                break
+            all_rows.append(new_rows), all_eta.append(n_eta), all_l.append(n_l)
+            try:
+                qp.add_rows(new_rows, n_eta, n_l)
+            except _hip.HipError as e:
+                if e.code != _hip.SCP_ERR_CAPACITY:
+                    raise
+                # restart this QP with a larger solver and every row collected so far
+                import torch
+
+                rows_cat, eta_cat, l_cat = torch.cat(all_rows), torch.cat(all_eta), torch.cat(all_l)
+                qp = self._grow_qp(int(rows_cat.numel()))
+                qp.reset(x)
+                qp.add_rows(rows_cat, eta_cat, l_cat)
+
+        self._last_qp_info = dict(info, **total, rounds=len(added), added=added)
+        if info["status_val"] not in (1, 2):  # scp.py:446-447
+            self._print(f"Warning: OSQP status {info['status']}")
+        return x
+
+    # ------------------------------------------------------------------------------------------------
+    # a8: avoidance check (scp.py:597-615)
+    # ------------------------------------------------------------------------------------------------
+    def _fast_check_avoidance_constraints(self, positions):
+        """True when every pair keeps ||p_i - p_j|| >= R - 0.01 at every stored sample; otherwise prints the first
+        violation in k -> i -> j order exactly like the reference (scp.py:602-615)."""
+        import torch
+
+        pos = positions if isinstance(positions, torch.Tensor) else self._ctx.tensor(np.asarray(positions, dtype=float))
+        pos = pos.reshape(self.N, self.K, self.D).contiguous()
+        q0, q1 = self.shard.pair_range()
+        _, first, _, _ = self._ctx.check_avoidance(self.N, self.K, self.D, self.R, pos, q0, q1)
+        first = self.shard.all_min_int(first)
+        if first >= (1 << 63) - 1:
+            return True
+        pairs = self.shard.pairs
+        k, q = divmod(first, pairs)
+        i, j = pair_from_index(q, self.N)
+        d = float(torch.linalg.vector_norm(pos[i, k] - pos[j, k]).item())
+        self._print(
+            f"Avoidance constraint violation at timestep {k} between vehicles {i} and {j}: distance = {d:.3f}"
+        )
+        return False
+
+    # ------------------------------------------------------------------------------------------------
+    # visualisation passthroughs (scp.py:644-840): host-side matplotlib over the stored numpy trajectories
+    # ------------------------------------------------------------------------------------------------
+    def visualize_trajectories(self, show_animation=False, save_path="trajectories.pdf"):
+        if self.trajectories is None:
+            raise ValueError("Trajectories not generated yet")  # scp.py:646-647
+        from ..viz.plot_trajectories import plot_trajectories
+
+        return plot_trajectories(self, show=show_animation, save_path=save_path)
+
+    def visualize_time_snapshots(self, num_snapshots=5, save_path=None):
+        if self.trajectories is None:
+            raise ValueError("Trajectories not generated yet")  # scp.py:782-783
+        from ..viz.plot_trajectories import plot_time_snapshots
+
+        return plot_time_snapshots(self, num_snapshots=num_snapshots, save_path=save_path)
+
+
+def pair_from_index(q, N):
+    """Lexicographic pair index -> (i, j), i < j (host helper, exact integer arithmetic)."""
+    i = int(((2 * N - 1) - np.sqrt(float((2 * N - 1) ** 2 - 8 * q))) // 2)
+    i = max(0, min(i, N - 2))
+    off = lambda a: a * (2 * N - a - 1) // 2
+    while off(i) > q:
+        i -= 1
+    while i < N - 2 and off(i + 1) <= q:
+        i += 1
+    return i, int(q - off(i) + i + 1)

@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""SCP iterations/sec (N agents x K waypoints) on MI355X -- the metric of BASELINE.json.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W                     (N > 1: one rank per GPU over RCCL)
+
+Workload (config.workload): 1024 agents x 50 timesteps, 2-D, fp64, grid-swap scenario seed 1000*N,
+h = 0.2 s, T = 10 s, R = 0.8 m -- BASELINE.json configs[2] (configs[1] "64 x 50" is a parity-test case).
+One step = one pass of the SCP loop body (scp.py:152-166): linearise ALL N(N-1)/2*K pairs around the previous
+trajectories, solve the joint QP (fixed rows + collision rows, exact constraint generation), relative-step test.
+Every step is the FIRST SCP iteration after QP#0 (the heaviest one: largest violations, most ADMM iterations), run
+from the same device-resident state, so each timed step is identical work; inputs are in HBM before timing starts.
+With N > 1 the same problem is split over the ranks (pair-range sharding of the O(N^2 K) passes, allgather of the
+per-shard trajectories and compact working rows): total work is fixed -> "scaling": "strong".
+
+The JSON line also carries
+  roofline     : the pairwise linearisation kernel (HBM-write bound): algorithmic bytes per launch / its average
+                 duration, measured live with HIP events around that launch on the stream it runs on;
+  cpu_baseline : the CPU oracle (oracle/, numpy restatement of the same algorithm = "port") timed on rank 0's host
+                 on a bounded sample of the same step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "ba-path-planning_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def cpu_baseline(N, K, D, h, T, R, space, p0, pf, margin, step_info, x0):
+    """Oracle (numpy port, 1 core) on a bounded sample of the same step; extrapolated with the step's own
+    ADMM-iteration and round counts (the oracle runs the identical algorithm, see tests/test_scp_gpu.py)."""
+    import numpy as np
+
+    from oracle import qp_oracle as qo
+    from oracle import scp_oracle as so
+
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+    except Exception:
+        pass
+    prob = so.make_problem(N, T, h, R, space, p0, pf)
+    pos, _ = so.kinematics(prob, x0)  # x0: the step's input state (QP#0 solution), same data as the GPU step
+    t = time.perf_counter()
+    eta, l_col, dist = so.linearize_pairs(prob, pos)
+    t_lin = time.perf_counter() - t
+    times = {}
+    for m in (1, 2, 8):  # m = 1 is an untimed warm-up of the allocator / caches
+        st = qo.Settings(max_iter=m, max_rounds=1, margin=margin, check_termination=10 ** 6)
+        t = time.perf_counter()
+        qo.admm_structured(prob, eta, l_col, dist, x0=x0, st=st)
+        times[m] = time.perf_counter() - t
+    # admm_structured ends every round with one full violation pass; t(m) = setup + m * t_it + t_viol
+    t_it = max((times[8] - times[2]) / 6.0, 1e-9)
+    t = time.perf_counter()
+    so.collision_apply(prob, eta, x0.ravel())
+    t_viol = time.perf_counter() - t
+    step_s = t_lin + step_info["rounds"] * t_viol + step_info["iter"] * t_it
+    return {
+        "value": 1.0 / step_s,
+        "unit": "SCP iterations/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": (f"numpy oracle, 1 thread: full linearisation pass {t_lin:.2f}s + full violation pass {t_viol:.2f}s x "
+                   f"{step_info['rounds']} rounds + {t_it*1e3:.1f} ms/ADMM iteration (measured over 6 iterations) x "
+                   f"{step_info['iter']} iterations of the same step = {step_s:.1f}s per SCP iteration (extrapolated)"),
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--agents", type=int, default=1024)
+    ap.add_argument("--timesteps", type=int, default=50)
+    ap.add_argument("--dim", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from path_planning.scenarios.position_generator import generate_grid_swap
+    from path_planning.solvers.scp import SCP
+
+    N, K, D, h, R = args.agents, args.timesteps, args.dim, 0.2, 0.8
+    T = K * h + 1e-9
+    p0, pf, space = generate_grid_swap(N, seed=1000 * N, dim=D)
+    solver = SCP(N, T, h, R, space, dim=D, device=local_rank, verbose=False, rank=rank, world_size=world)
+    assert solver.K == K
+    solver.set_initial_states(p0)
+    solver.set_final_states(pf)
+    # untimed setup: bounds, QP#0, device-resident starting state
+    solver._precompute_constraint_matrices()
+    acc0 = solver._solve_initial_trajectory()
+    pp = solver._ensure_pairs()
+
+    def step():
+        new = solver._solve_with_avoidance_constraints(acc0)
+        rel = solver._ctx.rel_step(new, acc0)[2]
+        return new, rel
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    lin_ms, viol_ms, infos = [], [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, rel = step()
+        lin_ms.append(pp.last_linearize_ms)
+        viol_ms.append(pp.last_violations_ms)
+        infos.append(dict(solver._last_qp_info, rel_step=rel))
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # roofline of the dominant pairwise kernel (per rank: its own shard of rows)
+    rows = pp.rows
+    alg_bytes = rows * 8 * (D + 1) + 2 * N * K * D * 8  # 24 B/row (D=2) + the two trajectory arrays
+    avg_ms = float(np.mean(lin_ms)) if lin_ms else float("nan")
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    out = {
+        "metric": "SCP iterations/sec (N agents x K waypoints)",
+        "value": args.steps / dt,
+        "unit": "SCP iterations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{N} agents x {K} timesteps, {D}-D, grid-swap seed {1000*N}; step = first SCP iteration after QP#0 "
+                        f"(linearise {N*(N-1)//2*K} rows + joint QP + rel-step)",
+            "agents": N, "timesteps": K, "dim": D, "collision_rows": N * (N - 1) // 2 * K,
+            "parallelism": f"pair-range shard x{world}" if world > 1 else "single GPU",
+            "qp": {k: infos[-1][k] for k in ("iter", "cg_iters_total", "working_rows", "rounds", "status", "rho_updates")},
+            "rel_step": infos[-1]["rel_step"],
+        },
+        "roofline": {
+            "kernel": "pair_pass_kernel<D,LINEARIZE> (scp_linearize_pairs)",
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "bytes_per_launch": alg_bytes, "rows_per_launch": rows, "avg_launch_ms": avg_ms,
+            "violations_pass_avg_ms": float(np.mean(viol_ms)) if viol_ms else None,
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N, K, D, h, T, R, space, p0, pf, solver.working_set_margin, infos[-1],
+                                           acc0.cpu().numpy())
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    else:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

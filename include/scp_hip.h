@@ -91,6 +91,9 @@ int scp_ctx_create(int device, void* hip_stream /* hipStream_t or NULL for the d
 void scp_ctx_destroy(scp_ctx* ctx);
 const char* scp_last_error(const scp_ctx* ctx);
 int scp_ctx_synchronize(scp_ctx* ctx);
+/* device time (ms) of the most recent pairwise kernel launch alone (scp_linearize_pairs, scp_check_avoidance,
+ * scp_collision_violations), from HIP events recorded on the ctx stream around that launch; synchronises. */
+int scp_ctx_last_pair_ms(scp_ctx* ctx, float* ms);
 
 /* ---- a4 / a7: SCP._compute_positions_velocities (scp.py:371-397),
  *               SCP._accelerations_to_positions_velocities (scp.py:559-595) ---------------------------

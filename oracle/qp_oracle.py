@@ -196,7 +196,7 @@ class Settings:
     adaptive_rho: bool = True
     adaptive_rho_interval: int = 25
     adaptive_rho_tolerance: float = 5.0
-    cg_iters: int = 10        # PCG iterations per ADMM step (fixed count; warm started)
+    cg_iters: int = 5         # PCG iterations per ADMM step (fixed count; warm started)
     cg_tol: float = 0.0       # optional early exit: ||r||_2 <= cg_tol * ||rhs||_2
     margin: float = 0.5       # initial working set: rows with dist_prev - R < margin
     feas_tol: float = 1e-6    # a non-working row enters W when (A x)_r < l_r - feas_tol
@@ -426,8 +426,9 @@ def scp_solve(prob: so.Problem, max_iterations=15, st: Settings | None = None, f
 
     `is_feasible` is evaluated once on QP#0's trajectory and never refreshed (scp.py:144, :152).
     force_iterations: run exactly that many loop bodies regardless of the flags (bench mode)."""
-    st = st or Settings()
-    x, _, info0 = admm_structured(prob, st=st)
+    st = st or Settings(max_iter=10000)  # scp.py:442
+    st0 = dataclasses.replace(st, max_iter=min(st.max_iter, 4000))  # OSQP default for QP#0 (scp.py:360)
+    x, _, info0 = admm_structured(prob, st=st0)
     if info0["status_val"] not in (1, 2):  # scp.py:363-365
         raise RuntimeError(f"OSQP failed: {info0['status']}")
     infos = [info0]

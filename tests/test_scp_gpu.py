@@ -1,0 +1,142 @@
+"""End-to-end GPU parity: path_planning.solvers.scp.SCP (HIP path through the C-ABI) against the oracle's SCP
+loop (oracle/qp_oracle.py:scp_solve) on identical scenarios, plus size-independent properties at the sizes of
+BASELINE.json's configs 2 and 3."""
+import numpy as np
+import pytest
+
+from oracle import qp_oracle as qo
+from oracle import scp_oracle as so
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-7  # fp64 tolerance on waypoints, GPU vs CPU oracle, same algorithm and settings
+
+
+def ref_scenario(n, seed):
+    from path_planning.scenarios.position_generator import generate_positions
+
+    return generate_positions(n, 0.8, seed=seed)
+
+
+def solve_gpu(n, T, h, R, space, p0, pf, max_iterations=15, dim=2, **kw):
+    from path_planning.solvers.scp import SCP
+
+    s = SCP(n_vehicles=n, time_horizon=T, time_step=h, min_distance=R, space_dims=space, dim=dim, verbose=False, **kw)
+    s.set_initial_states(p0)
+    s.set_final_states(pf)
+    traj = s.generate_trajectories(max_iterations=max_iterations)
+    return s, traj
+
+
+@pytest.mark.parametrize("n,seed,T,h", [(4, 1, 10.0, 0.5), (10, 7, 10.0, 0.2)])
+def test_scp_matches_oracle(n, seed, T, h):
+    p0, pf = ref_scenario(n, seed)
+    s, traj = solve_gpu(n, T, h, 0.8, [0, 0, 20, 20], p0, pf)
+    prob = so.make_problem(n, T, h, 0.8, [0, 0, 20, 20], p0, pf)
+    out = qo.scp_solve(prob, 15, qo.Settings(max_iter=10000))
+    assert s.last_info["n_iterations"] == out["iterations"]
+    assert s.last_info["converged"] == out["converged"]
+    assert s.last_info["qp0"]["iter"] == out["infos"][0]["iter"]
+    for a, b in zip(s.last_info["iterations"], out["infos"][1:]):
+        assert a["iter"] == b["iter"] and a["working_rows"] == b["working_rows"] and a["rounds"] == b["rounds"]
+    np.testing.assert_allclose([i["rel_step"] for i in s.last_info["iterations"]], out["rel_steps"], rtol=1e-6)
+    for key in ("positions", "velocities", "accelerations"):
+        assert traj[key].shape == (n, prob.K, 2) and traj[key].dtype == np.float64
+        np.testing.assert_allclose(traj[key], out[key], rtol=0, atol=TOL)
+
+
+def check_solution_properties(s, traj, tol=3e-2):
+    """Constraints of the reference QP hold at the returned point, to the ADMM termination tolerance
+    eps_abs + eps_rel * max(|Ax|, |z|) = 1e-3 * (1 + ~20 m)."""
+    N, K, D, h = s.N, s.K, s.D, s.h
+    a, v, p = traj["accelerations"], traj["velocities"], traj["positions"]
+    p0 = s.initial_positions.reshape(N, D)
+    pf = s.final_positions.reshape(N, D)
+    # kinematics consistency (bitwise the reference recurrences)
+    prob = so.make_problem(N, s.T, h, s.R, list(s.pos_min) + list(s.pos_max), p0, pf)
+    pos_o, vel_o = so.kinematics(prob, a)
+    np.testing.assert_array_equal(p, pos_o)
+    np.testing.assert_array_equal(v, vel_o)
+    # stored sample K-1 is NOT the goal; the goal is reached at the unstored state K
+    pK = p[:, K - 1] + h * v[:, K - 1] + 0.5 * h * h * a[:, K - 1]
+    vK = v[:, K - 1] + h * a[:, K - 1]
+    assert np.abs(pK - pf).max() < tol and np.abs(vK).max() < tol
+    assert np.abs(a).max() <= 15 + tol and np.abs(v).max() <= 2 + tol
+    assert np.abs(np.diff(a, axis=1)).max() / h <= 20 + tol
+    assert (p >= s.pos_min - tol).all() and (p <= s.pos_max + tol).all()
+
+
+def test_scp_grid_swap_64_config2():
+    """BASELINE config 2 (64 agents x 50 steps), D=2: solve, properties, and collision-free result."""
+    from path_planning.scenarios.position_generator import generate_grid_swap
+
+    p0, pf, space = generate_grid_swap(64, seed=64000)
+    s, traj = solve_gpu(64, 10.0, 0.2, 0.8, space, p0, pf)
+    check_solution_properties(s, traj)
+    prob = so.make_problem(64, 10.0, 0.2, 0.8, space, p0, pf)
+    assert s.last_info["n_iterations"] >= 1
+    if s.last_info["converged"]:
+        assert so.min_pair_distance(prob, traj["positions"]) >= 0.8 - 0.02
+
+
+def test_scp_3d_z0_metamorphic():
+    """D=3 with z == 0 reproduces the D=2 trajectories (the reference is strictly 2-D)."""
+    p0, pf = ref_scenario(6, 3)
+    s2, t2 = solve_gpu(6, 10.0, 0.5, 0.8, [0, 0, 20, 20], p0, pf)
+    z = np.zeros((6, 1))
+    s3, t3 = solve_gpu(6, 10.0, 0.5, 0.8, [0, 0, -5, 20, 20, 5], np.hstack([p0, z]), np.hstack([pf, z]), dim=3)
+    assert s2.last_info["n_iterations"] == s3.last_info["n_iterations"]
+    np.testing.assert_allclose(t3["positions"][:, :, :2], t2["positions"], rtol=0, atol=1e-9)
+    assert np.abs(t3["positions"][:, :, 2]).max() < 1e-12
+
+
+def test_scp_3d_grid_swap_config2():
+    """BASELINE config 2 names 3-D: 64 agents x 50 steps in 3-D against the oracle's first iterations."""
+    from path_planning.scenarios.position_generator import generate_grid_swap
+
+    p0, pf, space = generate_grid_swap(64, seed=7, dim=3)
+    s, traj = solve_gpu(64, 10.0, 0.2, 0.8, space, p0, pf, max_iterations=2, dim=3)
+    check_solution_properties(s, traj)
+    prob = so.make_problem(64, 10.0, 0.2, 0.8, space, p0, pf)
+    out = qo.scp_solve(prob, 2, qo.Settings(max_iter=10000))
+    assert s.last_info["n_iterations"] == out["iterations"]
+    np.testing.assert_allclose(traj["positions"], out["positions"], rtol=0, atol=TOL)
+
+
+def test_api_surface_and_errors(capsys):
+    from path_planning.solvers.scp import SCP
+
+    s = SCP(n_vehicles=3, time_horizon=3.0, time_step=0.2, min_distance=0.5, space_dims=[-5, -5, 500, 200])
+    out = capsys.readouterr().out
+    assert "---=== SCP Problem initialized ===---" in out and "Number of timesteps: 15" in out  # scp.py:93-97
+    assert (s.N, s.K, s.T, s.h, s.R) == (3, 15, 3.0, 0.2, 0.5)
+    assert s.convergence_tolerance == 1.5e-2 and (s.vel_min, s.vel_max, s.acc_max, s.jerk_max) == (-2, 2, 15.0, 20)
+    with pytest.raises(ValueError, match="Trajectories not generated yet"):
+        s.visualize_trajectories()
+    with pytest.raises(ValueError, match="Trajectories not generated yet"):
+        s.visualize_time_snapshots()
+    with pytest.raises(AssertionError):
+        s.set_initial_states(np.zeros((4, 2)))
+    # QP#0 infeasible (goal unreachable in T) -> RuntimeError("OSQP failed: ...") like scp.py:363-365
+    s = SCP(n_vehicles=2, time_horizon=1.0, time_step=0.2, min_distance=0.5, verbose=False,
+            qp_settings={"max_iter0": 200})
+    s.set_initial_states(np.array([[1.0, 1.0], [3.0, 3.0]]))
+    s.set_final_states(np.array([[19.0, 19.0], [15.0, 3.0]]))
+    with pytest.raises(RuntimeError, match="OSQP failed"):
+        s.generate_trajectories()
+
+
+def test_initially_feasible_skips_loop():
+    """Agents that never come close: is_feasible is True after QP#0 and the loop body never runs (scp.py:152)."""
+    p0 = np.array([[2.0, 2.0], [2.0, 18.0]])
+    pf = np.array([[18.0, 2.0], [18.0, 18.0]])
+    s, traj = solve_gpu(2, 10.0, 0.5, 0.8, [0, 0, 20, 20], p0, pf)
+    assert s.last_info["n_iterations"] == 0 and s.last_info["initially_feasible"]
+    check_solution_properties(s, traj)
+
+
+def test_plots_headless(tmp_path):
+    p0, pf = ref_scenario(4, 1)
+    s, _ = solve_gpu(4, 10.0, 0.5, 0.8, [0, 0, 20, 20], p0, pf, max_iterations=1)
+    s.visualize_trajectories(save_path=str(tmp_path / "t.pdf"))
+    s.visualize_time_snapshots(num_snapshots=3, save_path=str(tmp_path / "s.pdf"))
+    assert (tmp_path / "t.pdf").stat().st_size > 0 and (tmp_path / "s.pdf").stat().st_size > 0

@@ -21,6 +21,10 @@ struct scp_ctx {
   bool pair_timed;
   double* tm_scratch;     // time-major copy of a trajectory array for the pairwise passes (grown on demand)
   size_t tm_bytes;
+  uint32_t* cmp_map;      // scratch bitmap of the violations pass (self-cleaning), grown on demand
+  size_t cmp_map_bytes;
+  uint32_t* cmp_tot;      // per-block totals / offsets of the bitmap compaction
+  size_t cmp_tot_bytes;
 };
 
 static inline int scp_fail(scp_ctx* ctx, int code, const char* fmt, ...) {

@@ -4,6 +4,7 @@
 #include "scp_common.h"
 
 #include <cmath>
+#include <cstdlib>
 
 // ----------------------------------------------------------------------------------------------------
 // context
@@ -34,6 +35,8 @@ extern "C" void scp_ctx_destroy(scp_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->d_scratch);
+  if (ctx->cmp_map) (void)hipFree(ctx->cmp_map);
+  if (ctx->cmp_tot) (void)hipFree(ctx->cmp_tot);
   if (ctx->tm_scratch) (void)hipFree(ctx->tm_scratch);
   (void)hipHostFree(ctx->h_scratch);
   (void)hipEventDestroy(ctx->ev0);
@@ -346,8 +349,9 @@ __device__ inline void atomic_max_double(double* addr, double v) {
 }
 
 constexpr int PAIR_THREADS = 256;
-constexpr int PAIR_RPT = 16;                         // rows per thread (as 8 steps of 2 adjacent rows)
-constexpr int PAIR_ROWS = PAIR_THREADS * PAIR_RPT;   // rows (= pairs at one k) per workgroup
+constexpr int PAIR_STEPS = 8;                              // steps per thread, 2 adjacent rows per step
+constexpr int PAIR_UNROLL = 4;                             // independent steps in flight per thread
+constexpr int PAIR_ROWS = PAIR_THREADS * PAIR_STEPS * 2;   // rows (= pairs at one k) per workgroup
 
 enum PairMode { MODE_LINEARIZE = 0, MODE_CHECK = 1, MODE_VIOLATIONS = 2 };
 
@@ -355,191 +359,325 @@ struct PairArgs {
   int N, K, D;
   double R, h;
   int64_t q_begin, q_end, pairs;
-  const double* pos_tm;  // [K][N][D] time-major positions (prev for linearize, new for violations)
-  const double* p0;      // [N][D]
-  const double* v0;      // [N][D]
+  const double* P_tm;    // [K][N][D] time-major positions (linearize / check)
+  const double* Q_tm;    // [K][N][D] time-major acceleration displacement Q = P - (p0 + k h v0)
   double* eta;           // [D][eta_stride]
   int64_t eta_stride;    // scp_eta_stride(K, nq): K*nq rounded up to even (16-byte aligned planes)
   double* l;             // [K*nq]
   double margin;         // linearize: selection margin; violations: feas_tol
-  int64_t* sel_rows;
-  int64_t sel_cap;
-  uint32_t* bitmap;
+  const uint32_t* bitmap;  // working-set membership (read by the violations pass)
+  uint32_t* mark;          // bits set by this pass: the bitmap itself (linearize) or a scratch map (violations)
   scp_pair_stats* stats;
+  int ablate;            // developer switch (env SCP_PAIR_ABLATE): 1 = skip the streaming stores, 2 = force no-LDS
 };
 
-// One workgroup = PAIR_ROWS consecutive local rows of one time step k.  The k-slice of the trajectory array
-// (and of p0, v0) is staged in LDS once per workgroup: every row then costs two LDS reads per array
-// (P_i broadcast within the wave, P_j consecutive lanes -> consecutive 8*D-byte slots), and the only HBM
-// traffic is the fully coalesced, 16-byte-per-lane streaming write (linearize) or read (violations) of the
-// compact rows: 8*(D+1) bytes per row.
+// [N][K][D] -> time-major P and Q = P - (p0 + (k h) v0) (either output may be NULL)
+__global__ __launch_bounds__(256) void pair_prep_kernel(int N, int K, int D, double h, const double* __restrict__ pos,
+                                                         const double* __restrict__ p0,
+                                                         const double* __restrict__ v0, double* __restrict__ P_tm,
+                                                         double* __restrict__ Q_tm) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;  // destination index (coalesced writes)
+  const int64_t C = (int64_t)N * D;
+  if (t >= C * K) return;
+  const int k = (int)(t / C);
+  const int c = (int)(t % C);
+  const int i = c / D, d = c % D;
+  const double p = pos[((int64_t)i * K + k) * D + d];
+  if (P_tm) P_tm[t] = p;
+  if (Q_tm) Q_tm[t] = p - (p0[c] + ((double)k * h) * v0[c]);
+}
+
+// move a lexicographic pair (i, j) forward by s pairs; row i+1 of the triangle starts at j = i + 2
+__device__ inline void pair_advance(int& i, int& j, int N, int s) {
+  j += s;
+  while (j >= N && i < N) {
+    j -= N - 2 - i;
+    ++i;
+  }
+}
+
+// 1/sqrt(x) to fp64 accuracy from the hardware seed: two Newton steps
+__device__ inline double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double hx = 0.5 * x;
+  y = y * fma(-hx * y, y, 1.5);
+  y = y * fma(-hx * y, y, 1.5);
+  return y;
+}
+
+template <int D>
+struct Pt {
+  double v[D];
+};
+
+template <int D>
+__device__ inline Pt<D> load_pt(const double* base, int idx) {
+  Pt<D> r;
+  if (D == 2) {
+    const double2 t = *reinterpret_cast<const double2*>(base + 2 * idx);
+    r.v[0] = t.x;
+    r.v[1] = t.y;
+  } else {
+#pragma unroll
+    for (int d = 0; d < D; ++d) r.v[d] = base[D * idx + d];
+  }
+  return r;
+}
+
+// One workgroup = PAIR_ROWS consecutive local rows of one time step k.  The k-slices of P and Q are staged in
+// LDS once per workgroup (16-byte loads): every row then costs four LDS reads (P_i, Q_i broadcast within the
+// wave; P_j, Q_j: consecutive lanes -> consecutive 8*D-byte slots, conflict free), and the only HBM traffic is
+// the fully coalesced, 16-byte-per-lane streaming write (linearize) or read (violations) of the compact rows:
+// 8*(D+1) bytes per row.  PAIR_UNROLL independent steps per thread keep loads/stores and the fp64 chains of
+// several rows in flight; the selection / first-violation bookkeeping is behind a wave-uniform ballot.
 template <int D, int MODE, bool USE_LDS>
 __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
-  extern __shared__ double lds[];
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   const int N = a.N;
   const int k = blockIdx.y;
   const int64_t nq = a.q_end - a.q_begin;
   const int64_t slice0 = (int64_t)k * nq;       // first local row of this k
   const int64_t par = slice0 & 1;               // keep every thread's first row at an even local row id
   const int64_t c0 = (int64_t)blockIdx.x * PAIR_ROWS - par;  // first local pair offset of this workgroup
+  constexpr bool NEED_P = MODE != MODE_VIOLATIONS;
+  constexpr bool NEED_Q = MODE != MODE_CHECK;
 
-  const double* Pg = a.pos_tm + (int64_t)k * N * D;
-  const double* P;
-  const double* P0;
-  const double* V0;
+  const double* P = NEED_P ? a.P_tm + (int64_t)k * N * D : nullptr;
+  const double* Q = NEED_Q ? a.Q_tm + (int64_t)k * N * D : nullptr;
   if (USE_LDS) {
     double* sP = lds;
-    double* sP0 = lds + (int64_t)N * D;
-    double* sV0 = lds + 2 * (int64_t)N * D;
-    for (int t = threadIdx.x; t < N * D; t += PAIR_THREADS) {
-      sP[t] = Pg[t];
-      if (MODE != MODE_CHECK) {
-        sP0[t] = a.p0[t];
-        sV0[t] = a.v0[t];
-      }
+    double* sQ = lds + (NEED_P ? (int64_t)N * D : 0);
+    const int n2 = (N * D) >> 1;  // slices are 16-byte aligned: N*D*8 bytes from an aligned base, even count or tail
+    for (int t = threadIdx.x; t < n2; t += PAIR_THREADS) {
+      if (NEED_P) reinterpret_cast<double2*>(sP)[t] = reinterpret_cast<const double2*>(P)[t];
+      if (NEED_Q) reinterpret_cast<double2*>(sQ)[t] = reinterpret_cast<const double2*>(Q)[t];
+    }
+    if (((N * D) & 1) && threadIdx.x == 0) {
+      if (NEED_P) sP[N * D - 1] = P[N * D - 1];
+      if (NEED_Q) sQ[N * D - 1] = Q[N * D - 1];
     }
     __syncthreads();
     P = sP;
-    P0 = sP0;
-    V0 = sV0;
-  } else {
-    P = Pg;
-    P0 = a.p0;
-    V0 = a.v0;
+    Q = sQ;
   }
 
-  const double kh = (double)k * a.h;
   const double thr = a.R - 0.01;  // scp.py:610
-  double my_min = __longlong_as_double(0x7FF0000000000000LL);
-  double my_maxv = -my_min;
+  const double INF = __longlong_as_double(0x7FF0000000000000LL);
+  double my_min = INF, my_maxv = -INF;
   unsigned long long my_first = 0xFFFFFFFFFFFFFFFFULL;
 
+  // first pair of this thread
+  const int64_t off0 = c0 + 2 * threadIdx.x;
+  int ci = 0, cj = 1;
+  {
+    int64_t qf = a.q_begin + (off0 < 0 ? 0 : off0);
+    if (qf >= a.pairs) qf = a.pairs - 1;
+    decode_pair(qf, N, ci, cj);
+    if (off0 < 0) {  // thread 0 of the first workgroup of an odd slice: row -1 is masked, row 0 is (ci, cj)
+      cj -= 1;       // so that advancing by one lands on the first real pair
+    }
+  }
+
 #pragma unroll 1
-  for (int s = 0; s < PAIR_RPT / 2; ++s) {
-    const int64_t off = c0 + (int64_t)s * (2 * PAIR_THREADS) + 2 * threadIdx.x;  // local pair offset of row A
-    double eta_v[2][D];
-    double l_v[2];
-    bool valid[2], sel[2];
-    int64_t grow[2];
-    int i = 0, j = 0;
+  for (int s0 = 0; s0 < PAIR_STEPS; s0 += PAIR_UNROLL) {
+    double eta_v[PAIR_UNROLL][2][D];
+    double l_v[PAIR_UNROLL][2];
+    bool valid[PAIR_UNROLL][2];
+    bool sel[PAIR_UNROLL][2];
+    int pi_[PAIR_UNROLL][2], pj_[PAIR_UNROLL][2];
+    double ein[PAIR_UNROLL][2][D], lin_[PAIR_UNROLL][2];
+
+    // indices of the 2*PAIR_UNROLL rows of this group
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int64_t o = off + e;
-      valid[e] = (o >= 0) && (o < nq);
-      sel[e] = false;
-      grow[e] = 0;
-      l_v[e] = 0.0;
+    for (int u = 0; u < PAIR_UNROLL; ++u) {
+      const int64_t off = off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS);
+      valid[u][0] = (off >= 0) && (off < nq);
+      valid[u][1] = (off + 1 >= 0) && (off + 1 < nq);
+      pi_[u][0] = ci;
+      pj_[u][0] = cj;
+      int i1 = ci, j1 = cj;
+      pair_advance(i1, j1, N, 1);
+      pi_[u][1] = i1;
+      pj_[u][1] = j1;
+      pair_advance(ci, cj, N, 2 * PAIR_THREADS);
 #pragma unroll
-      for (int d = 0; d < D; ++d) eta_v[e][d] = 0.0;
-      if (!valid[e]) continue;
-      const int64_t q = a.q_begin + o;
-      if (e == 0 || !valid[0]) {
-        decode_pair(q, N, i, j);
-      } else {  // next pair in lexicographic order
-        if (++j >= N) {
-          ++i;
-          j = i + 1;
+      for (int e = 0; e < 2; ++e)
+        if (!valid[u][e] || pi_[u][e] >= N - 1 || pj_[u][e] >= N || pj_[u][e] <= pi_[u][e]) {
+          valid[u][e] = false;
+          pi_[u][e] = 0;
+          pj_[u][e] = N > 1 ? 1 : 0;
         }
-      }
-      grow[e] = (int64_t)k * a.pairs + q;
-      double diff[D];
-      double ss = 0.0;
+    }
+    uint32_t marked[PAIR_UNROLL];
+    if (MODE == MODE_VIOLATIONS) {  // streaming reads of the compact rows, all issued before use
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
-        diff[d] = P[i * D + d] - P[j * D + d];
-        ss += diff[d] * diff[d];
-      }
-      const double raw = sqrt(ss);
-      my_min = fmin(my_min, raw);
-      if (MODE != MODE_VIOLATIONS && raw < thr) {
-        const unsigned long long g = (unsigned long long)grow[e];
-        my_first = g < my_first ? g : my_first;
-      }
-      if (MODE == MODE_LINEARIZE) {
-        double dist = raw;
-        double eta[D];
-        if (raw < 1e-6) {  // scp.py:503-507 with a fixed direction instead of a random one
-          dist = 1.0;
+      for (int u = 0; u < PAIR_UNROLL; ++u) {
+        const int64_t lrA = slice0 + off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS);
+        // both rows of the step share one bitmap word (lrA is even); rows already in the working set stay out
+        marked[u] = (valid[u][0] || valid[u][1]) ? (a.bitmap[(lrA + (valid[u][0] ? 0 : 1)) >> 5] >> (lrA & 31)) & 3u : 0u;
+        if (valid[u][0] && valid[u][1]) {
 #pragma unroll
-          for (int d = 0; d < D; ++d) eta[d] = d == 0 ? 1.0 : 0.0;
+          for (int d = 0; d < D; ++d) {
+            const double2 t = *reinterpret_cast<const double2*>(a.eta + d * a.eta_stride + lrA);
+            ein[u][0][d] = t.x;
+            ein[u][1][d] = t.y;
+          }
+          const double2 t = *reinterpret_cast<const double2*>(a.l + lrA);
+          lin_[u][0] = t.x;
+          lin_[u][1] = t.y;
         } else {
-          const double inv = 1.0 / raw;
 #pragma unroll
-          for (int d = 0; d < D; ++d) eta[d] = diff[d] * inv;  // scp.py:509
-        }
-        double ip = 0.0, iv = 0.0, lin = 0.0;
+          for (int e = 0; e < 2; ++e) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-          ip += eta[d] * (P0[i * D + d] - P0[j * D + d]);  // scp.py:543
-          iv += eta[d] * (V0[i * D + d] - V0[j * D + d]);  // scp.py:544
-          lin += eta[d] * diff[d];                          // scp.py:547
-          eta_v[e][d] = eta[d];
+            for (int d = 0; d < D; ++d) ein[u][e][d] = valid[u][e] ? a.eta[d * a.eta_stride + lrA + e] : 0.0;
+            lin_[u][e] = valid[u][e] ? a.l[lrA + e] : 0.0;
+          }
         }
-        lin -= dist;
-        l_v[e] = a.R + lin - (ip + iv * kh);  // scp.py:549
-        sel[e] = (dist - a.R) < a.margin;
-      } else if (MODE == MODE_VIOLATIONS) {
-        // (A x)_r = eta . ((P_i - c_i) - (P_j - c_j)),  c = p0 + (k h) v0
-        const int64_t lr = slice0 + o;
-        double ax = 0.0;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          const double qi = P[i * D + d] - (P0[i * D + d] + kh * V0[i * D + d]);
-          const double qj = P[j * D + d] - (P0[j * D + d] + kh * V0[j * D + d]);
-          ax += a.eta[(int64_t)d * a.eta_stride + lr] * (qi - qj);
-        }
-        const double viol = a.l[lr] - ax;
-        my_maxv = fmax(my_maxv, viol);
-        sel[e] = viol > a.margin;
       }
     }
 
-    if (MODE == MODE_LINEARIZE) {
-      const int64_t lrA = slice0 + off;  // even by construction
-      const int64_t stride = a.eta_stride;
-      if (valid[0] && valid[1]) {
+    bool any_sel = false;
 #pragma unroll
-        for (int d = 0; d < D; ++d)
-          *reinterpret_cast<double2*>(a.eta + d * stride + lrA) = make_double2(eta_v[0][d], eta_v[1][d]);
-        *reinterpret_cast<double2*>(a.l + lrA) = make_double2(l_v[0], l_v[1]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-          if (valid[e]) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) a.eta[d * stride + lrA + e] = eta_v[e][d];
-            a.l[lrA + e] = l_v[e];
-          }
-      }
-    }
-    if (MODE != MODE_CHECK) {
+    for (int u = 0; u < PAIR_UNROLL; ++u) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        bool take = sel[e];
-        if (take) {
-          const int64_t lr = slice0 + off + e;
-          const uint32_t bit = 1u << (lr & 31);
-          const uint32_t old = atomicOr(a.bitmap + (lr >> 5), bit);
-          if (MODE == MODE_VIOLATIONS) take = (old & bit) == 0;  // rows already in the working set stay out
+        const int i = pi_[u][e], j = pj_[u][e];
+        sel[u][e] = false;
+        if (MODE != MODE_VIOLATIONS) {
+          const Pt<D> Pi = load_pt<D>(P, i), Pj = load_pt<D>(P, j);
+          double diff[D], ss = 0.0;
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            diff[d] = Pi.v[d] - Pj.v[d];
+            ss = fma(diff[d], diff[d], ss);
+          }
+          const bool deg = ss < 1e-12;  // dist < 1e-6 (scp.py:503)
+          const double inv = rsqrt_nr(fmax(ss, 1e-200));
+          double raw = ss * inv;
+          raw = fma(fma(-raw, raw, ss), 0.5 * inv, raw);  // one correction step: sqrt to < 1 ulp (0 stays 0)
+          if (valid[u][e]) {
+            my_min = fmin(my_min, raw);
+            if (raw < thr) {
+              const int64_t off = off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS) + e;
+              const unsigned long long g = (unsigned long long)((int64_t)k * a.pairs + a.q_begin + off);
+              my_first = g < my_first ? g : my_first;
+            }
+          }
+          if (MODE == MODE_LINEARIZE) {
+            const Pt<D> Qi = load_pt<D>(Q, i), Qj = load_pt<D>(Q, j);
+            const double dist = deg ? 1.0 : raw;  // scp.py:503-507 with the fixed direction e_0
+            double qd = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+              const double e_d = deg ? (d == 0 ? 1.0 : 0.0) : diff[d] * inv;  // scp.py:509
+              eta_v[u][e][d] = e_d;
+              qd = fma(e_d, Qi.v[d] - Qj.v[d], qd);
+            }
+            // l = R + (eta.diff - dist) - eta.(c_i - c_j) = R - dist + eta.(Q_i - Q_j)  (scp.py:543-549), where the
+            // reference's eta.diff term is kept for the degenerate rule (there eta.diff != dist)
+            l_v[u][e] = (a.R - dist) + qd;
+            sel[u][e] = valid[u][e] && ((dist - a.R) < a.margin);
+          }
+        } else {
+          const Pt<D> Qi = load_pt<D>(Q, i), Qj = load_pt<D>(Q, j);
+          double ax = 0.0;
+#pragma unroll
+          for (int d = 0; d < D; ++d) ax = fma(ein[u][e][d], Qi.v[d] - Qj.v[d], ax);
+          const double viol = lin_[u][e] - ax;
+          if (valid[u][e]) my_maxv = fmax(my_maxv, viol);
+          sel[u][e] = valid[u][e] && (viol > a.margin) && !((marked[u] >> e) & 1u);
         }
-        wave_append(take, grow[e], a.sel_rows, a.sel_cap, (unsigned long long*)&a.stats->n_selected);
+        any_sel |= sel[u][e];
+      }
+    }
+
+    if (MODE == MODE_LINEARIZE && (a.ablate & 1)) {
+#pragma unroll
+      for (int u = 0; u < PAIR_UNROLL; ++u)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) my_maxv = fmax(my_maxv, l_v[u][e] + eta_v[u][e][0] + eta_v[u][e][D - 1]);
+    }
+    if (MODE == MODE_LINEARIZE && !(a.ablate & 1)) {
+#pragma unroll
+      for (int u = 0; u < PAIR_UNROLL; ++u) {
+        const int64_t lrA = slice0 + off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS);  // even by construction
+        if (valid[u][0] && valid[u][1]) {
+#pragma unroll
+          for (int d = 0; d < D; ++d)
+            *reinterpret_cast<double2*>(a.eta + d * a.eta_stride + lrA) = make_double2(eta_v[u][0][d], eta_v[u][1][d]);
+          *reinterpret_cast<double2*>(a.l + lrA) = make_double2(l_v[u][0], l_v[u][1]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            if (valid[u][e]) {
+#pragma unroll
+              for (int d = 0; d < D; ++d) a.eta[d * a.eta_stride + lrA + e] = eta_v[u][e][d];
+              a.l[lrA + e] = l_v[u][e];
+            }
+        }
+      }
+    }
+    if (MODE != MODE_CHECK && any_sel) {
+      // Selected rows (a few in 10^4) only set their bit -- no-return atomics on distinct words, no shared
+      // counter: a returning same-address atomic per wave cost 3x the whole streaming pass.  The row list is
+      // produced afterwards from the bitmap by the compaction kernels below (sorted, deterministic).
+#pragma unroll
+      for (int u = 0; u < PAIR_UNROLL; ++u) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          if (sel[u][e]) {
+            const int64_t lr = slice0 + off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS) + e;
+            atomicOr(a.mark + (lr >> 5), 1u << (lr & 31));
+          }
+        }
       }
     }
   }
 
-  // wavefront reductions -> one atomic per wave
-  my_min = wave_min(my_min);
-  my_first = wave_min_u64(my_first);
-  if (MODE == MODE_VIOLATIONS) my_maxv = wave_max(my_maxv);
+  // wavefront reductions, then one candidate per WORKGROUP; the global atomic is issued only when a relaxed
+  // (L1-bypassing) read says the candidate would improve the result: same-address atomics retire at < 100 per
+  // microsecond chip-wide, 25 600 of them (one per wave) would cost more than the whole streaming pass.
+  __shared__ double red_d[PAIR_THREADS / 64];
+  __shared__ unsigned long long red_u[PAIR_THREADS / 64];
+  if (MODE != MODE_VIOLATIONS) {
+    my_min = wave_min(my_min);
+    my_first = wave_min_u64(my_first);
+  } else {
+    my_maxv = wave_max(my_maxv);
+  }
   if ((threadIdx.x & 63) == 0) {
-    if (my_min < __longlong_as_double(0x7FF0000000000000LL)) atomic_min_pos_double(&a.stats->min_dist, my_min);
-    if (my_first != 0xFFFFFFFFFFFFFFFFULL) atomicMin((unsigned long long*)&a.stats->first_violation, my_first);
-    if (MODE == MODE_VIOLATIONS && my_maxv > -__longlong_as_double(0x7FF0000000000000LL))
-      atomic_max_double(&a.stats->max_violation, my_maxv);
+    red_d[threadIdx.x >> 6] = MODE != MODE_VIOLATIONS ? my_min : my_maxv;
+    red_u[threadIdx.x >> 6] = my_first;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (MODE != MODE_VIOLATIONS) {
+      double m = red_d[0];
+      unsigned long long f = red_u[0];
+#pragma unroll
+      for (int w = 1; w < PAIR_THREADS / 64; ++w) {
+        m = fmin(m, red_d[w]);
+        f = red_u[w] < f ? red_u[w] : f;
+      }
+      const double cur = __hip_atomic_load(&a.stats->min_dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (m < cur) atomic_min_pos_double(&a.stats->min_dist, m);
+      if ((a.ablate & 1) && my_maxv == 12345.678) a.stats->max_violation = my_maxv;  // keeps the ablated values live
+      if (f != 0xFFFFFFFFFFFFFFFFULL) {
+        const unsigned long long curf = __hip_atomic_load((unsigned long long*)&a.stats->first_violation,
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f < curf) atomicMin((unsigned long long*)&a.stats->first_violation, f);
+      }
+    } else {
+      double m = red_d[0];
+#pragma unroll
+      for (int w = 1; w < PAIR_THREADS / 64; ++w) m = fmax(m, red_d[w]);
+      const double cur = __hip_atomic_load(&a.stats->max_violation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (m > cur) atomic_max_double(&a.stats->max_violation, m);
+    }
   }
 }
 
-// scratch for the time-major copy of the trajectory array (grown on demand, owned by the ctx)
+// scratch for the time-major slices (grown on demand, owned by the ctx)
 static int ensure_tm(scp_ctx* ctx, size_t bytes) {
   if (ctx->tm_bytes >= bytes) return SCP_OK;
   if (ctx->tm_scratch) {
@@ -554,18 +692,26 @@ static int ensure_tm(scp_ctx* ctx, size_t bytes) {
 }
 
 template <int MODE>
-static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_layout) {
+static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_layout, const double* p0,
+                            const double* v0) {
   const int N = a.N, K = a.K, D = a.D;
   const int64_t nq = a.q_end - a.q_begin;
-  int rc = ensure_tm(ctx, (size_t)N * K * D * sizeof(double));
+  const size_t slice = ((size_t)N * K * D + 1) & ~(size_t)1;  // keep the second array 16-byte aligned
+  int rc = ensure_tm(ctx, 2 * slice * sizeof(double));
   if (rc) return rc;
-  rc = scp_launch_to_time_major(ctx, N, K, D, pos_ref_layout, ctx->tm_scratch);
-  if (rc) return rc;
-  a.pos_tm = ctx->tm_scratch;
+  double* P_tm = MODE != MODE_VIOLATIONS ? ctx->tm_scratch : nullptr;
+  double* Q_tm = MODE != MODE_CHECK ? ctx->tm_scratch + slice : nullptr;
+  hipLaunchKernelGGL(pair_prep_kernel, dim3(scp_cdiv((int64_t)N * K * D, 256)), dim3(256), 0, ctx->stream, N, K, D,
+                     a.h, pos_ref_layout, p0, v0, P_tm, Q_tm);
+  a.P_tm = P_tm;
+  a.Q_tm = Q_tm;
   hipLaunchKernelGGL(pair_stats_init_kernel, dim3(1), dim3(1), 0, ctx->stream, a.stats);
   if (nq <= 0) return SCP_OK;
-  const size_t lds_bytes = (size_t)(MODE == MODE_CHECK ? 1 : 3) * N * D * sizeof(double);
-  const bool use_lds = lds_bytes <= 64 * 1024;
+  const size_t lds_bytes = (size_t)(MODE == MODE_LINEARIZE ? 2 : 1) * N * D * sizeof(double);
+  // the k-slice must start 16-byte aligned in global memory for the double2 staging loads: N*D even
+  const char* abl = getenv("SCP_PAIR_ABLATE");
+  a.ablate = abl ? atoi(abl) : 0;
+  const bool use_lds = lds_bytes <= 64 * 1024 && ((N * D) % 2 == 0) && !(a.ablate & 2);
   dim3 grid(scp_cdiv(nq + 1, PAIR_ROWS), K);
   dim3 block(PAIR_THREADS);
   SCP_HIP_CHECK(ctx, hipEventRecord(ctx->pair_ev0, ctx->stream));
@@ -594,6 +740,135 @@ extern "C" int scp_ctx_last_pair_ms(scp_ctx* ctx, float* ms) {
   return SCP_OK;
 }
 
+// ----------------------------------------------------------------------------------------------------
+// bitmap -> sorted row list (three tiny launches; the list order is the row order, hence deterministic)
+// ----------------------------------------------------------------------------------------------------
+constexpr int CMP_THREADS = 256;
+constexpr int CMP_WPT = 4;                              // bitmap words per thread
+constexpr int CMP_WORDS = CMP_THREADS * CMP_WPT;        // per workgroup
+
+__device__ inline int block_exclusive_scan(int v, int* total) {
+  __shared__ int wsum[CMP_THREADS / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < CMP_THREADS / 64; ++w) {
+    if (w < wave) base += wsum[w];
+    tot += wsum[w];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+__global__ __launch_bounds__(CMP_THREADS) void compact_count_kernel(const uint32_t* __restrict__ map, int64_t words,
+                                                                     uint32_t* __restrict__ block_tot) {
+  const int64_t w0 = (int64_t)blockIdx.x * CMP_WORDS + (int64_t)threadIdx.x * CMP_WPT;
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < CMP_WPT; ++i)
+    if (w0 + i < words) c += __popc(map[w0 + i]);
+  int tot;
+  block_exclusive_scan(c, &tot);
+  if (threadIdx.x == 0) block_tot[blockIdx.x] = (uint32_t)tot;
+}
+
+// exclusive scan of the block totals in place (one workgroup; nblocks is a few hundred), total -> stats
+__global__ __launch_bounds__(CMP_THREADS) void compact_scan_kernel(uint32_t* __restrict__ block_tot, int nblocks,
+                                                                    scp_pair_stats* __restrict__ stats) {
+  int carry = 0;
+  for (int b0 = 0; b0 < nblocks; b0 += CMP_THREADS) {
+    const int b = b0 + threadIdx.x;
+    const int v = b < nblocks ? (int)block_tot[b] : 0;
+    int tot;
+    const int ex = block_exclusive_scan(v, &tot);
+    if (b < nblocks) block_tot[b] = (uint32_t)(carry + ex);
+    carry += tot;
+  }
+  if (threadIdx.x == 0) stats->n_selected = (unsigned long long)carry;
+}
+
+// write the global row id of every set bit; optionally merge the map into `merge_into` and clear it
+__global__ __launch_bounds__(CMP_THREADS) void compact_write_kernel(uint32_t* __restrict__ map, int64_t words,
+                                                                     const uint32_t* __restrict__ block_off, int64_t nq,
+                                                                     int64_t q_begin, int64_t pairs,
+                                                                     int64_t* __restrict__ rows, int64_t cap,
+                                                                     uint32_t* __restrict__ merge_into) {
+  const int64_t w0 = (int64_t)blockIdx.x * CMP_WORDS + (int64_t)threadIdx.x * CMP_WPT;
+  uint32_t wd[CMP_WPT];
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < CMP_WPT; ++i) {
+    wd[i] = (w0 + i < words) ? map[w0 + i] : 0u;
+    c += __popc(wd[i]);
+  }
+  int tot;
+  int64_t slot = (int64_t)block_off[blockIdx.x] + block_exclusive_scan(c, &tot);
+  if (tot == 0) return;
+#pragma unroll
+  for (int i = 0; i < CMP_WPT; ++i) {
+    uint32_t m = wd[i];
+    if (m && merge_into) {
+      merge_into[w0 + i] |= m;
+      map[w0 + i] = 0u;
+    }
+    while (m) {
+      const int bit = __ffs((int)m) - 1;
+      m &= m - 1;
+      const int64_t lr = (w0 + i) * 32 + bit;
+      if (slot < cap) rows[slot] = (lr / nq) * pairs + q_begin + (lr % nq);
+      ++slot;
+    }
+  }
+}
+
+static int ensure_cmp(scp_ctx* ctx, int64_t words) {
+  const size_t need_map = (size_t)words * sizeof(uint32_t);
+  const size_t need_tot = (size_t)(scp_cdiv(words, CMP_WORDS) + 1) * sizeof(uint32_t);
+  if (ctx->cmp_map_bytes < need_map) {
+    if (ctx->cmp_map) {
+      SCP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      SCP_HIP_CHECK(ctx, hipFree(ctx->cmp_map));
+      ctx->cmp_map = nullptr;
+      ctx->cmp_map_bytes = 0;
+    }
+    SCP_HIP_CHECK(ctx, hipMalloc(&ctx->cmp_map, need_map));
+    SCP_HIP_CHECK(ctx, hipMemsetAsync(ctx->cmp_map, 0, need_map, ctx->stream));  // self-cleaning afterwards
+    ctx->cmp_map_bytes = need_map;
+  }
+  if (ctx->cmp_tot_bytes < need_tot) {
+    if (ctx->cmp_tot) {
+      SCP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      SCP_HIP_CHECK(ctx, hipFree(ctx->cmp_tot));
+      ctx->cmp_tot = nullptr;
+      ctx->cmp_tot_bytes = 0;
+    }
+    SCP_HIP_CHECK(ctx, hipMalloc(&ctx->cmp_tot, need_tot));
+    ctx->cmp_tot_bytes = need_tot;
+  }
+  return SCP_OK;
+}
+
+static int launch_compaction(scp_ctx* ctx, uint32_t* map, int64_t words, int64_t nq, int64_t q_begin, int64_t pairs,
+                             int64_t* rows, int64_t cap, uint32_t* merge_into, scp_pair_stats* stats) {
+  if (words <= 0) return SCP_OK;
+  const int nblocks = scp_cdiv(words, CMP_WORDS);
+  hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(CMP_THREADS), 0, ctx->stream, map, words, ctx->cmp_tot);
+  hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(CMP_THREADS), 0, ctx->stream, ctx->cmp_tot, nblocks, stats);
+  hipLaunchKernelGGL(compact_write_kernel, dim3(nblocks), dim3(CMP_THREADS), 0, ctx->stream, map, words, ctx->cmp_tot,
+                     nq, q_begin, pairs, rows, cap, merge_into);
+  SCP_HIP_CHECK(ctx, hipGetLastError());
+  return SCP_OK;
+}
+
 static int check_pair_range(scp_ctx* ctx, int N, int K, int D, int64_t q_begin, int64_t q_end) {
   SCP_REQUIRE(ctx, N >= 1 && K >= 1 && (D == 2 || D == 3), "pair pass: bad shape N=%d K=%d D=%d", N, K, D);
   SCP_REQUIRE(ctx, q_begin >= 0 && q_end >= q_begin && q_end <= scp_pairs(N),
@@ -618,12 +893,16 @@ extern "C" int scp_linearize_pairs(scp_ctx* ctx, int N, int K, int D, double R, 
   PairArgs a{};
   a.N = N; a.K = K; a.D = D; a.R = R; a.h = h;
   a.q_begin = q_begin; a.q_end = q_end; a.pairs = scp_pairs(N);
-  a.p0 = p0; a.v0 = v0; a.eta = eta_out; a.l = l_out; a.margin = margin;
-  a.sel_rows = sel_rows; a.sel_cap = sel_cap; a.bitmap = sel_bitmap; a.stats = stats;
+  a.eta = eta_out; a.l = l_out; a.margin = margin;
+  a.bitmap = sel_bitmap; a.mark = sel_bitmap; a.stats = stats;
   a.eta_stride = scp_eta_stride(K, nq);
-  const size_t words = (size_t)((K * nq + 31) / 32);
-  if (words) SCP_HIP_CHECK(ctx, hipMemsetAsync(sel_bitmap, 0, words * sizeof(uint32_t), ctx->stream));
-  return launch_pair_pass<MODE_LINEARIZE>(ctx, a, pos_prev);
+  const int64_t words = (K * nq + 31) / 32;
+  rc = ensure_cmp(ctx, words);
+  if (rc) return rc;
+  if (words) SCP_HIP_CHECK(ctx, hipMemsetAsync(sel_bitmap, 0, (size_t)words * sizeof(uint32_t), ctx->stream));
+  rc = launch_pair_pass<MODE_LINEARIZE>(ctx, a, pos_prev, p0, v0);
+  if (rc) return rc;
+  return launch_compaction(ctx, sel_bitmap, words, nq, q_begin, a.pairs, sel_rows, sel_cap, nullptr, stats);
 }
 
 extern "C" int scp_check_avoidance(scp_ctx* ctx, int N, int K, int D, double R, int64_t q_begin, int64_t q_end,
@@ -636,7 +915,7 @@ extern "C" int scp_check_avoidance(scp_ctx* ctx, int N, int K, int D, double R, 
   a.N = N; a.K = K; a.D = D; a.R = R; a.h = 0.0;
   a.q_begin = q_begin; a.q_end = q_end; a.pairs = scp_pairs(N);
   a.stats = stats;
-  return launch_pair_pass<MODE_CHECK>(ctx, a, pos);
+  return launch_pair_pass<MODE_CHECK>(ctx, a, pos, nullptr, nullptr);
 }
 
 extern "C" int scp_collision_violations(scp_ctx* ctx, int N, int K, int D, double h, int64_t q_begin,
@@ -651,10 +930,17 @@ extern "C" int scp_collision_violations(scp_ctx* ctx, int N, int K, int D, doubl
   PairArgs a{};
   a.N = N; a.K = K; a.D = D; a.R = 0.0; a.h = h;
   a.q_begin = q_begin; a.q_end = q_end; a.pairs = scp_pairs(N);
-  a.p0 = p0; a.v0 = v0; a.eta = const_cast<double*>(eta); a.l = const_cast<double*>(l_col); a.margin = feas_tol;
-  a.sel_rows = new_rows; a.sel_cap = new_cap; a.bitmap = sel_bitmap; a.stats = stats;
-  a.eta_stride = scp_eta_stride(K, q_end - q_begin);
-  return launch_pair_pass<MODE_VIOLATIONS>(ctx, a, pos);
+  a.eta = const_cast<double*>(eta); a.l = const_cast<double*>(l_col); a.margin = feas_tol;
+  const int64_t nq = q_end - q_begin;
+  const int64_t words = (K * nq + 31) / 32;
+  rc = ensure_cmp(ctx, words);
+  if (rc) return rc;
+  a.bitmap = sel_bitmap; a.mark = ctx->cmp_map; a.stats = stats;
+  a.eta_stride = scp_eta_stride(K, nq);
+  rc = launch_pair_pass<MODE_VIOLATIONS>(ctx, a, pos, p0, v0);
+  if (rc) return rc;
+  // new rows = bits of the scratch map; merging them into the working-set bitmap also clears the scratch map
+  return launch_compaction(ctx, ctx->cmp_map, words, nq, q_begin, a.pairs, new_rows, new_cap, sel_bitmap, stats);
 }
 
 // ----------------------------------------------------------------------------------------------------

@@ -41,7 +41,7 @@ def make_qp(ctx, prob, **kw):
 
 
 def oracle_settings(**kw):
-    base = dict(cg_iters=5)
+    base = dict(cg_iters=3)
     base.update(kw)
     return qo.Settings(**base)
 

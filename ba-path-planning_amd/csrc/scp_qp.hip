@@ -17,52 +17,10 @@
 // Device layout: every vector lives time-major, [rows][C] with C = N*D columns (c = i*D + d).  Fixed rows are
 // stacked as  [0,K-1) jerk | [K-1,2K-1) acc | [2K-1,3K-1) vel | [3K-1,4K-1) pos.
 // oracle/qp_oracle.py:admm_structured is the line-by-line CPU statement of this file.
-#include "scp_common.h"
+#include "scp_qp_internal.h"
 
 #include <cmath>
 #include <vector>
-
-namespace {
-
-constexpr int NPART = 128;  // partial sums of a dot product (fixed -> deterministic summation order)
-
-enum Slot {  // device scalar slots (doubles)
-  SL_RZ0 = 0, SL_RZ1 = 1,
-  SL_RP = 8, SL_NAX = 9, SL_NZ = 10, SL_RD = 11, SL_NPX = 12, SL_NATY = 13,
-  SL_COUNT = 32
-};
-
-struct QpDev {
-  // constant blocks
-  double *F, *Ft, *S0, *S0t, *HS, *Hf, *Minv, *aug, *wrow;
-  // fixed rows
-  double *lf, *uf, *zf, *yf, *wf, *tf;
-  // x-space vectors [K][C]
-  double *x, *xt, *rhs, *r, *p, *zz, *G;
-  double* HQ;  // [2K][C]: rows [0,K) = H v, rows [K,2K) = S0 v
-  // working rows
-  int64_t* w_row;
-  int *w_k, *w_i, *w_j;
-  double *w_eta, *w_l, *zc, *yc;
-  // scalars
-  double* scal;   // SL_COUNT
-  double* part;   // 2 * NPART
-};
-
-}  // namespace
-
-struct scp_qp {
-  scp_ctx* ctx;
-  int N, K, D, Rf;
-  int64_t C;
-  double h;
-  scp_qp_settings st;
-  int64_t row_cap, nW;
-  bool problem_set, reset_done;
-  double rho;
-  QpDev d;
-  double* h_scal;  // pinned
-};
 
 // ----------------------------------------------------------------------------------------------------
 // kernels
@@ -436,7 +394,8 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.zc = c.take<double>((size_t)cap);
   d.yc = c.take<double>((size_t)cap);
   d.scal = c.take<double>(SL_COUNT);
-  d.part = c.take<double>(2 * NPART);
+  d.part = c.take<double>(2 * SCP_PART_CAP);
+  d.hpf = c.take<double>(nx);
   return c.off;
 }
 
@@ -755,6 +714,7 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
   scp_ctx* ctx = qp->ctx;
   if (!qp->reset_done) return scp_fail(ctx, SCP_ERR_STATE, "qp_solve: call scp_qp_reset first");
   SCP_REQUIRE(ctx, info, "qp_solve: null info");
+  const bool fused = qp->st.use_mfma == 1 && qp->K <= SCP_FUSED_MAX_K && (qp->C + 15) / 16 <= SCP_PART_CAP / 2;
   const scp_qp_settings& st = qp->st;
   memset(info, 0, sizeof(*info));
   info->status_val = -2;  // OSQP_MAX_ITER_REACHED
@@ -763,7 +723,8 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
   double rp = INFINITY, rd = INFINITY;
   while (it < st.max_iter) {
     ++it;
-    QP_CHECK(admm_iteration(qp, &cg_total));
+    if (fused) QP_CHECK(scp_qp_fused_iteration(qp, &cg_total));
+    else QP_CHECK(admm_iteration(qp, &cg_total));
     if (it % st.check_termination == 0 || it >= st.max_iter) {
       QP_CHECK(residuals(qp));
       const double* hs = qp->h_scal;

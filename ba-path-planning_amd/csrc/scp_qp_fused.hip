@@ -1,0 +1,457 @@
+// Column-block kernels of the joint QP (fused path, K <= SCP_FUSED_MAX_K).
+//
+// Every operation of an ADMM step except the working-row gather/scatter is local to a column c = (agent, axis):
+// the fixed rows, the K x K KKT block and the Toeplitz block S0 act along the time index only.
+// One workgroup (4 waves) therefore owns 16 columns, keeps their K-vectors as [rows][16] tiles in LDS and chains
+// whole sequences of products  tile_out = A . tile_in  (A one of F^T, [H_f; S0], S0^T, H_f^{-1}, F) on the fp64
+// matrix cores -- v_mfma_f64_16x16x4_f64, one 16 x 16 output tile per wave and step, the A operand preloaded from
+// L2 in chunks of 16 k-steps so that a chain costs one memory latency, not one per step.  Kernel boundaries remain
+// only where the algorithm needs the whole grid: the two PCG inner products and the row gather/scatter.
+// An ADMM step with 3 PCG steps is 16 launches (45 on the generic path of scp_qp.hip, which stays as the fallback
+// for K > 128 and as the use_mfma = 0/2 reference); the arithmetic is the same, statement by statement.
+#include "scp_qp_internal.h"
+
+namespace {
+
+constexpr int CB = 16;         // columns per workgroup
+constexpr int FT = 256;        // threads per workgroup
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// O[R][16] = (ACC ? O : 0) + A[R][M] . V[M][16];  A: global, row-major, leading dimension M;  V, O: distinct LDS tiles.
+// Operand maps of v_mfma_f64_16x16x4_f64 as in scp_gemm.hip.  Caller synchronises before reading O.
+template <bool ACC>
+__device__ inline void wg_mm(const double* __restrict__ A, int R, int M, const double* V, double* O) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int tiles = (R + 15) >> 4;
+  for (int t = wave; t < tiles; t += FT / 64) {
+    const int r0 = t * 16;
+    const int arow = r0 + li;
+    const bool rok = arow < R;
+    const double* Ap = A + (size_t)(rok ? arow : 0) * M;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    if (ACC) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + lk + 4 * r;
+        acc[r] = row < R ? O[row * CB + li] : 0.0;
+      }
+    }
+    for (int kc = 0; kc < M; kc += 64) {
+      double a[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int kk = kc + 4 * s + lk;
+        a[s] = (rok && kk < M) ? Ap[kk] : 0.0;
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        if (kc + 4 * s < M) {  // wave-uniform
+          const int kk = kc + 4 * s + lk;
+          const double b = kk < M ? V[kk * CB + li] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b, acc, 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + lk + 4 * r;
+      if (row < R) O[row * CB + li] = acc[r];
+    }
+  }
+}
+
+// tile <-> global ([rows][C] slab, columns c0 .. c0+15); out-of-range columns read as 0 and are not written
+__device__ inline void tile_load(double* T, const double* __restrict__ g, int rows, int64_t C, int64_t c0) {
+  for (int e = threadIdx.x; e < rows * CB; e += FT) {
+    const int r = e >> 4, c = e & 15;
+    T[e] = (c0 + c < C) ? g[(int64_t)r * C + c0 + c] : 0.0;
+  }
+}
+__device__ inline void tile_store(const double* T, double* __restrict__ g, int rows, int64_t C, int64_t c0) {
+  for (int e = threadIdx.x; e < rows * CB; e += FT) {
+    const int r = e >> 4, c = e & 15;
+    if (c0 + c < C) g[(int64_t)r * C + c0 + c] = T[e];
+  }
+}
+__device__ inline void tile_zero_global(double* __restrict__ g, int rows, int64_t C, int64_t c0) {
+  for (int e = threadIdx.x; e < rows * CB; e += FT) {
+    const int r = e >> 4, c = e & 15;
+    if (c0 + c < C) g[(int64_t)r * C + c0 + c] = 0.0;
+  }
+}
+
+// deterministic workgroup sum (fixed tree); result valid in every thread
+__device__ inline double wg_sum(double v) {
+  __shared__ double s[FT / 64];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double t = (s[0] + s[1]) + (s[2] + s[3]);
+  __syncthreads();
+  return t;
+}
+
+// sum of the per-workgroup partials of an inner product, same order in every workgroup
+__device__ inline double sum_parts(const double* __restrict__ part, int n) {
+  double v = 0.0;
+  for (int b = threadIdx.x; b < n; b += FT) v += part[b];
+  return wg_sum(v);
+}
+
+// ---- K_A: rhs and the fixed part of the PCG start ------------------------------------------------------
+// W = rho w_r z_f - y_f ; rhsF = sigma x + F^T W ; [Hx ; Qx] = [H_f ; S0] x
+// has_rows: r0 = rhsF - Hx -> rhs, Qx -> Q, xt = x, G = 0        (PCG follows)
+// else    : xt = H_f^{-1} rhsF                                    (the x-update is exact)
+__global__ __launch_bounds__(FT) void fused_pre_kernel(int K, int Rf, int64_t C, double rho, double sigma, int has_rows,
+                                                        const double* __restrict__ Ft, const double* __restrict__ HS,
+                                                        const double* __restrict__ Minv,
+                                                        const double* __restrict__ wrow, const double* __restrict__ x,
+                                                        const double* __restrict__ zf, const double* __restrict__ yf,
+                                                        double* __restrict__ rhs, double* __restrict__ Q,
+                                                        double* __restrict__ xt, double* __restrict__ G) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* X = lds;                  // [K][16]
+  double* W = X + K * CB;           // [Rf][16]
+  double* T1 = W + Rf * CB;         // [K][16]
+  double* T2 = T1 + K * CB;         // [2K][16]
+  const int64_t c0 = (int64_t)blockIdx.x * CB;
+  tile_load(X, x, K, C, c0);
+  for (int e = threadIdx.x; e < Rf * CB; e += FT) {
+    const int r = e >> 4, c = e & 15;
+    const int64_t g = (int64_t)r * C + c0 + c;
+    W[e] = (c0 + c < C) ? rho * wrow[r] * zf[g] - yf[g] : 0.0;
+  }
+  __syncthreads();
+  wg_mm<false>(Ft, K, Rf, W, T1);
+  if (has_rows) wg_mm<false>(HS, 2 * K, K, X, T2);
+  __syncthreads();
+  for (int e = threadIdx.x; e < K * CB; e += FT) T1[e] += sigma * X[e];  // rhsF
+  __syncthreads();
+  if (has_rows) {
+    for (int e = threadIdx.x; e < K * CB; e += FT) {
+      const int r = e >> 4, c = e & 15;
+      if (c0 + c < C) {
+        const int64_t g = (int64_t)r * C + c0 + c;
+        rhs[g] = T1[e] - T2[e];
+        Q[g] = T2[K * CB + e];
+        xt[g] = X[e];
+        G[g] = 0.0;
+      }
+    }
+  } else {
+    wg_mm<false>(Minv, K, K, T1, T2);
+    __syncthreads();
+    tile_store(T2, xt, K, C, c0);
+  }
+}
+
+// ---- K_B / K_D: working rows, G += eta g ----------------------------------------------------------------
+//   INIT: g = rho zc - yc - rho eta.(Qx_i - Qx_j)     (rhs minus H x of the collision part)
+//   HMUL: g = rho eta.(Qp_i - Qp_j)
+template <int D, bool INIT>
+__global__ __launch_bounds__(256) void fused_rows_kernel(int64_t nW, int64_t C, double rho, const int* __restrict__ wk,
+                                                          const int* __restrict__ wi, const int* __restrict__ wj,
+                                                          const double* __restrict__ weta,
+                                                          const double* __restrict__ zc, const double* __restrict__ yc,
+                                                          const double* __restrict__ Q, double* __restrict__ G) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= nW) return;
+  const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
+  const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
+  double e[D], ax = 0.0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    e[d] = weta[n * D + d];
+    ax += e[d] * (Q[bi + d] - Q[bj + d]);
+  }
+  double g = rho * ax;
+  if (INIT) g = (rho * zc[n] - yc[n]) - g;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const double c = e[d] * g;
+    atomicAdd(G + bi + d, c);
+    atomicAdd(G + bj + d, -c);
+  }
+}
+
+// ---- K_C: PCG start ---------------------------------------------------------------------------------------
+// r = r0 + S0^T G ; zz = Minv r ; p = zz ; part[b] = r.zz ; [HpF ; Qp] = [H_f ; S0] p ; G = 0
+__global__ __launch_bounds__(FT) void fused_cg_init_kernel(int K, int64_t C, const double* __restrict__ S0t,
+                                                            const double* __restrict__ Minv,
+                                                            const double* __restrict__ HS, const double* __restrict__ r0,
+                                                            double* __restrict__ G, double* __restrict__ r,
+                                                            double* __restrict__ p, double* __restrict__ hpf,
+                                                            double* __restrict__ Q, double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* Gt = lds;                 // [K][16]
+  double* R = Gt + K * CB;          // [K][16]
+  double* Z = R + K * CB;           // [K][16]
+  double* T2 = Z + K * CB;          // [2K][16]
+  const int64_t c0 = (int64_t)blockIdx.x * CB;
+  tile_load(Gt, G, K, C, c0);
+  tile_load(R, r0, K, C, c0);
+  __syncthreads();
+  tile_zero_global(G, K, C, c0);
+  wg_mm<true>(S0t, K, K, Gt, R);
+  __syncthreads();
+  wg_mm<false>(Minv, K, K, R, Z);
+  __syncthreads();
+  wg_mm<false>(HS, 2 * K, K, Z, T2);
+  double dot = 0.0;
+  for (int e = threadIdx.x; e < K * CB; e += FT) dot += R[e] * Z[e];
+  dot = wg_sum(dot);  // (barrier inside: T2 complete afterwards)
+  if (threadIdx.x == 0) part[blockIdx.x] = dot;
+  for (int e = threadIdx.x; e < K * CB; e += FT) {
+    const int rr = e >> 4, c = e & 15;
+    if (c0 + c < C) {
+      const int64_t g = (int64_t)rr * C + c0 + c;
+      r[g] = R[e];
+      p[g] = Z[e];
+      hpf[g] = T2[e];
+      Q[g] = T2[K * CB + e];
+    }
+  }
+}
+
+// ---- K_E: Hp = HpF + S0^T G ; part[b] = p.Hp ; G = 0 -----------------------------------------------------
+__global__ __launch_bounds__(FT) void fused_cg_hp_kernel(int K, int64_t C, const double* __restrict__ S0t,
+                                                          double* __restrict__ G, const double* __restrict__ hpf,
+                                                          const double* __restrict__ p, double* __restrict__ Hp,
+                                                          double* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* Gt = lds;                 // [K][16]
+  double* H = Gt + K * CB;          // [K][16]
+  const int64_t c0 = (int64_t)blockIdx.x * CB;
+  tile_load(Gt, G, K, C, c0);
+  tile_load(H, hpf, K, C, c0);
+  __syncthreads();
+  tile_zero_global(G, K, C, c0);
+  wg_mm<true>(S0t, K, K, Gt, H);
+  __syncthreads();
+  double dot = 0.0;
+  for (int e = threadIdx.x; e < K * CB; e += FT) {
+    const int rr = e >> 4, c = e & 15;
+    if (c0 + c < C) {
+      const int64_t g = (int64_t)rr * C + c0 + c;
+      Hp[g] = H[e];
+      dot += p[g] * H[e];
+    }
+  }
+  dot = wg_sum(dot);
+  if (threadIdx.x == 0) part[blockIdx.x] = dot;
+}
+
+// ---- K_F: alpha = rz / pHp ; xt += alpha p ; r -= alpha Hp ; zz = Minv r ; part[b] = r.zz -------------------
+// rz: first = 1 -> sum(part_rz) (the PCG start wrote partials), else scal[slot]
+__global__ __launch_bounds__(FT) void fused_cg_step_kernel(int K, int64_t C, int nblk, int first, int slot,
+                                                            const double* __restrict__ Minv, double* __restrict__ scal,
+                                                            const double* __restrict__ part_rz,
+                                                            const double* __restrict__ part_php,
+                                                            const double* __restrict__ p, const double* __restrict__ Hp,
+                                                            double* __restrict__ xt, double* __restrict__ r,
+                                                            double* __restrict__ zz, double* __restrict__ part_new) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* R = lds;                  // [K][16]
+  double* Z = R + K * CB;           // [K][16]
+  const int64_t c0 = (int64_t)blockIdx.x * CB;
+  const double rz = first ? sum_parts(part_rz, nblk) : scal[slot];
+  const double pHp = sum_parts(part_php, nblk);
+  const double alpha = (pHp > 0.0 && rz != 0.0) ? rz / pHp : 0.0;
+  if (first && blockIdx.x == 0 && threadIdx.x == 0) scal[slot] = rz;
+  for (int e = threadIdx.x; e < K * CB; e += FT) {
+    const int rr = e >> 4, c = e & 15;
+    double v = 0.0;
+    if (c0 + c < C) {
+      const int64_t g = (int64_t)rr * C + c0 + c;
+      xt[g] += alpha * p[g];
+      v = r[g] - alpha * Hp[g];
+      r[g] = v;
+    }
+    R[e] = v;
+  }
+  __syncthreads();
+  wg_mm<false>(Minv, K, K, R, Z);
+  __syncthreads();
+  double dot = 0.0;
+  for (int e = threadIdx.x; e < K * CB; e += FT) dot += R[e] * Z[e];
+  dot = wg_sum(dot);
+  if (threadIdx.x == 0) part_new[blockIdx.x] = dot;
+  tile_store(Z, zz, K, C, c0);
+}
+
+// ---- K_G: beta = rz_new / rz ; p = zz + beta p ; [HpF ; Qp] = [H_f ; S0] p ; scal[slot^1] = rz_new ------------
+__global__ __launch_bounds__(FT) void fused_cg_dir_kernel(int K, int64_t C, int nblk, int slot,
+                                                           const double* __restrict__ HS, double* __restrict__ scal,
+                                                           const double* __restrict__ part_new,
+                                                           const double* __restrict__ zz, double* __restrict__ p,
+                                                           double* __restrict__ hpf, double* __restrict__ Q) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* P = lds;                  // [K][16]
+  double* T2 = P + K * CB;          // [2K][16]
+  const int64_t c0 = (int64_t)blockIdx.x * CB;
+  const double rz = scal[slot];
+  const double rz_new = sum_parts(part_new, nblk);
+  const double beta = rz != 0.0 ? rz_new / rz : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) scal[slot ^ 1] = rz_new;
+  for (int e = threadIdx.x; e < K * CB; e += FT) {
+    const int rr = e >> 4, c = e & 15;
+    double v = 0.0;
+    if (c0 + c < C) {
+      const int64_t g = (int64_t)rr * C + c0 + c;
+      v = zz[g] + beta * p[g];
+      p[g] = v;
+    }
+    P[e] = v;
+  }
+  __syncthreads();
+  wg_mm<false>(HS, 2 * K, K, P, T2);
+  __syncthreads();
+  for (int e = threadIdx.x; e < K * CB; e += FT) {
+    const int rr = e >> 4, c = e & 15;
+    if (c0 + c < C) {
+      const int64_t g = (int64_t)rr * C + c0 + c;
+      hpf[g] = T2[e];
+      Q[g] = T2[K * CB + e];
+    }
+  }
+}
+
+// ---- K_U: z~ = F x~ ; relaxation, projection, duals of the fixed rows ; x = alpha x~ + (1-alpha) x ; Q = S0 x~ ---
+__global__ __launch_bounds__(FT) void fused_post_kernel(int K, int Rf, int64_t C, double rho, double alpha, int has_rows,
+                                                         const double* __restrict__ F, const double* __restrict__ S0,
+                                                         const double* __restrict__ wrow, const double* __restrict__ xt,
+                                                         const double* __restrict__ lf, const double* __restrict__ uf,
+                                                         double* __restrict__ zf, double* __restrict__ yf,
+                                                         double* __restrict__ x, double* __restrict__ Q) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* X = lds;                  // [K][16]
+  double* T = X + K * CB;           // [Rf][16]
+  double* Qt = T + Rf * CB;         // [K][16]
+  const int64_t c0 = (int64_t)blockIdx.x * CB;
+  tile_load(X, xt, K, C, c0);
+  __syncthreads();
+  wg_mm<false>(F, Rf, K, X, T);
+  if (has_rows) wg_mm<false>(S0, K, K, X, Qt);
+  __syncthreads();
+  for (int e = threadIdx.x; e < Rf * CB; e += FT) {
+    const int r = e >> 4, c = e & 15;
+    if (c0 + c < C) {
+      const int64_t g = (int64_t)r * C + c0 + c;
+      const double rr = rho * wrow[r];
+      const double zh = alpha * T[e] + (1.0 - alpha) * zf[g];
+      const double y = yf[g];
+      const double zn = fmin(fmax(zh + y / rr, lf[g]), uf[g]);
+      yf[g] = y + rr * (zh - zn);
+      zf[g] = zn;
+    }
+  }
+  for (int e = threadIdx.x; e < K * CB; e += FT) {
+    const int r = e >> 4, c = e & 15;
+    if (c0 + c < C) {
+      const int64_t g = (int64_t)r * C + c0 + c;
+      x[g] = alpha * X[e] + (1.0 - alpha) * x[g];
+      if (has_rows) Q[g] = Qt[e];
+    }
+  }
+}
+
+// ---- K_V: collision rows: relaxation, projection (u = +inf), duals ------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void fused_row_update_kernel(int64_t nW, int64_t C, double rho, double alpha,
+                                                                const int* __restrict__ wk, const int* __restrict__ wi,
+                                                                const int* __restrict__ wj,
+                                                                const double* __restrict__ weta,
+                                                                const double* __restrict__ wl,
+                                                                const double* __restrict__ Q, double* __restrict__ zc,
+                                                                double* __restrict__ yc) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= nW) return;
+  const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
+  const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
+  double tc = 0.0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) tc += weta[n * D + d] * (Q[bi + d] - Q[bj + d]);
+  const double zh = alpha * tc + (1.0 - alpha) * zc[n];
+  const double y = yc[n];
+  const double zn = fmax(zh + y / rho, wl[n]);
+  yc[n] = y + rho * (zh - zn);
+  zc[n] = zn;
+}
+
+#define FUSED_LAUNCHED(qp) SCP_HIP_CHECK((qp)->ctx, hipGetLastError())
+
+}  // namespace
+
+int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
+  const QpDev& d = qp->d;
+  hipStream_t s = qp->ctx->stream;
+  const int K = qp->K, Rf = qp->Rf;
+  const int64_t C = qp->C, nx = (int64_t)K * C;
+  const int nblk = (int)((C + CB - 1) / CB);
+  const int has_rows = qp->nW > 0 ? 1 : 0;
+  const dim3 cgrid(nblk), cblock(FT);
+  const dim3 rgrid((unsigned)((qp->nW + 255) / 256)), rblock(256);
+  const size_t tile = (size_t)CB * sizeof(double);
+  double* Q = d.HQ + nx;   // S0 v slab
+  double* Hp = d.HQ;       // H p slab
+  double* part_rz = d.part;
+  double* part_php = d.part + SCP_PART_CAP;
+
+  hipLaunchKernelGGL(fused_pre_kernel, cgrid, cblock, (size_t)(4 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.sigma,
+                     has_rows, d.Ft, d.HS, d.Minv, d.wrow, d.x, d.zf, d.yf, d.rhs, Q, d.xt, d.G);
+  FUSED_LAUNCHED(qp);
+  if (has_rows) {
+    if (qp->D == 2)
+      hipLaunchKernelGGL((fused_rows_kernel<2, true>), rgrid, rblock, 0, s, qp->nW, C, qp->rho, d.w_k, d.w_i, d.w_j,
+                         d.w_eta, d.zc, d.yc, Q, d.G);
+    else
+      hipLaunchKernelGGL((fused_rows_kernel<3, true>), rgrid, rblock, 0, s, qp->nW, C, qp->rho, d.w_k, d.w_i, d.w_j,
+                         d.w_eta, d.zc, d.yc, Q, d.G);
+    FUSED_LAUNCHED(qp);
+    hipLaunchKernelGGL(fused_cg_init_kernel, cgrid, cblock, (size_t)(5 * K) * tile, s, K, C, d.S0t, d.Minv, d.HS, d.rhs,
+                       d.G, d.r, d.p, d.hpf, Q, part_rz);
+    FUSED_LAUNCHED(qp);
+    int slot = SL_RZ0;
+    for (int it = 0; it < qp->st.cg_iters; ++it) {
+      if (qp->D == 2)
+        hipLaunchKernelGGL((fused_rows_kernel<2, false>), rgrid, rblock, 0, s, qp->nW, C, qp->rho, d.w_k, d.w_i, d.w_j,
+                           d.w_eta, d.zc, d.yc, Q, d.G);
+      else
+        hipLaunchKernelGGL((fused_rows_kernel<3, false>), rgrid, rblock, 0, s, qp->nW, C, qp->rho, d.w_k, d.w_i, d.w_j,
+                           d.w_eta, d.zc, d.yc, Q, d.G);
+      FUSED_LAUNCHED(qp);
+      hipLaunchKernelGGL(fused_cg_hp_kernel, cgrid, cblock, (size_t)(2 * K) * tile, s, K, C, d.S0t, d.G, d.hpf, d.p, Hp,
+                         part_php);
+      FUSED_LAUNCHED(qp);
+      // the step kernel reads part_rz (first step) or scal[slot], writes the new partials to the OTHER half of
+      // the rz array so that workgroups still summing the old partials are not disturbed
+      double* part_new = (it & 1) ? part_rz : part_rz + SCP_PART_CAP / 2;
+      double* part_old = (it & 1) ? part_rz + SCP_PART_CAP / 2 : part_rz;
+      hipLaunchKernelGGL(fused_cg_step_kernel, cgrid, cblock, (size_t)(2 * K) * tile, s, K, C, nblk, it == 0 ? 1 : 0, slot,
+                         d.Minv, d.scal, part_old, part_php, d.p, Hp, d.xt, d.r, d.zz, part_new);
+      FUSED_LAUNCHED(qp);
+      ++*cg_count;
+      if (it + 1 < qp->st.cg_iters) {
+        hipLaunchKernelGGL(fused_cg_dir_kernel, cgrid, cblock, (size_t)(3 * K) * tile, s, K, C, nblk, slot, d.HS, d.scal,
+                           part_new, d.zz, d.p, d.hpf, Q);
+        FUSED_LAUNCHED(qp);
+        slot ^= 1;
+      }
+    }
+  }
+  hipLaunchKernelGGL(fused_post_kernel, cgrid, cblock, (size_t)(2 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.alpha,
+                     has_rows, d.F, d.S0, d.wrow, d.xt, d.lf, d.uf, d.zf, d.yf, d.x, Q);
+  FUSED_LAUNCHED(qp);
+  if (has_rows) {
+    if (qp->D == 2)
+      hipLaunchKernelGGL(fused_row_update_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, qp->rho, qp->st.alpha, d.w_k, d.w_i,
+                         d.w_j, d.w_eta, d.w_l, Q, d.zc, d.yc);
+    else
+      hipLaunchKernelGGL(fused_row_update_kernel<3>, rgrid, rblock, 0, s, qp->nW, C, qp->rho, qp->st.alpha, d.w_k, d.w_i,
+                         d.w_j, d.w_eta, d.w_l, Q, d.zc, d.yc);
+    FUSED_LAUNCHED(qp);
+  }
+  return SCP_OK;
+}

@@ -1,0 +1,49 @@
+// Declarations shared by scp_qp.hip (ADMM driver, generic kernels) and scp_qp_fused.hip (column-block kernels).
+#pragma once
+#include "scp_common.h"
+
+constexpr int NPART = 128;  // partial sums of a dot product (fixed -> deterministic summation order)
+
+enum Slot {  // device scalar slots (doubles)
+  SL_RZ0 = 0, SL_RZ1 = 1,
+  SL_RP = 8, SL_NAX = 9, SL_NZ = 10, SL_RD = 11, SL_NPX = 12, SL_NATY = 13,
+  SL_COUNT = 32
+};
+
+struct QpDev {
+  // constant blocks
+  double *F, *Ft, *S0, *S0t, *HS, *Hf, *Minv, *aug, *wrow;
+  // fixed rows
+  double *lf, *uf, *zf, *yf, *wf, *tf;
+  // x-space vectors [K][C]
+  double *x, *xt, *rhs, *r, *p, *zz, *G;
+  double* HQ;  // [2K][C]: rows [0,K) = H v, rows [K,2K) = S0 v
+  // working rows
+  int64_t* w_row;
+  int *w_k, *w_i, *w_j;
+  double *w_eta, *w_l, *zc, *yc;
+  // scalars
+  double* scal;   // SL_COUNT
+  double* part;   // 2 * SCP_PART_CAP
+  double* hpf;    // [K][C]: H_f p of the fused PCG
+};
+
+struct scp_qp {
+  scp_ctx* ctx;
+  int N, K, D, Rf;
+  int64_t C;
+  double h;
+  scp_qp_settings st;
+  int64_t row_cap, nW;
+  bool problem_set, reset_done;
+  double rho;
+  QpDev d;
+  double* h_scal;  // pinned
+};
+
+
+// scp_qp_fused.hip: one ADMM iteration with the column-local chains fused into column-block kernels
+// (K <= SCP_FUSED_MAX_K).  Same arithmetic as admm_iteration() in scp_qp.hip.
+constexpr int SCP_FUSED_MAX_K = 64;   // (4K + 4K-1) * 128 B of LDS tiles must stay below 64 KiB
+constexpr int SCP_PART_CAP = 4096;  // capacity of each partial-sum array (column blocks of the fused path)
+int scp_qp_fused_iteration(scp_qp* qp, int* cg_count);

@@ -65,7 +65,9 @@ typedef struct scp_qp_settings {
   int32_t adaptive_rho_interval; /* 25 (iterations; multiple of check_termination) */
   double adaptive_rho_tolerance; /* 5 */
   int32_t cg_iters;              /* PCG iterations per ADMM step (fixed count, warm started) */
-  int32_t use_mfma;              /* 1: v_mfma_f64_16x16x4_f64 tiles for the dense K x K products; 0: VALU */
+  int32_t use_mfma;              /* 1: fused column-block kernels, every K-dimension product on
+                                    v_mfma_f64_16x16x4_f64 (K <= 64; larger K falls back to 2);
+                                    2: one MFMA product per launch (generic path); 0: VALU products */
 } scp_qp_settings;
 
 /* [host] result of scp_qp_solve */

@@ -2,7 +2,7 @@
 //
 // Every operation of an ADMM step except the working-row gather/scatter is local to a column c = (agent, axis):
 // the fixed rows, the K x K KKT block and the Toeplitz block S0 act along the time index only.
-// One workgroup (4 waves) therefore owns 16 columns, keeps their K-vectors as [rows][16] tiles in LDS and chains
+// One workgroup (8 waves) therefore owns 16 columns, keeps their K-vectors as [rows][16] tiles in LDS and chains
 // whole sequences of products  tile_out = A . tile_in  (A one of F^T, [H_f; S0], S0^T, H_f^{-1}, F) on the fp64
 // matrix cores -- v_mfma_f64_16x16x4_f64, one 16 x 16 output tile per wave and step, the A operand preloaded from
 // L2 in chunks of 16 k-steps so that a chain costs one memory latency, not one per step.  Kernel boundaries remain
@@ -14,17 +14,21 @@
 namespace {
 
 constexpr int CB = 16;         // columns per workgroup
-constexpr int FT = 256;        // threads per workgroup
+constexpr int FT = 512;        // threads per workgroup (8 waves)
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // O[R][16] = (ACC ? O : 0) + A[R][M] . V[M][16];  A: global, row-major, leading dimension M;  V, O: distinct LDS tiles.
+// The waves [w0, w0+nw) of the workgroup share the row tiles; other waves return at once, so two independent
+// products can run side by side on disjoint wave sets.  The A operands of the NEXT chunk of 16 k-steps are loaded
+// while the MFMAs of the current chunk issue (one L2 latency per product instead of one per chunk).
 // Operand maps of v_mfma_f64_16x16x4_f64 as in scp_gemm.hip.  Caller synchronises before reading O.
 template <bool ACC>
-__device__ inline void wg_mm(const double* __restrict__ A, int R, int M, const double* V, double* O) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ inline void wg_mm(const double* __restrict__ A, int R, int M, const double* V, double* O, int w0, int nw) {
+  const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) - w0;
+  if (wave < 0 || wave >= nw) return;
   const int li = lane & 15, lk = lane >> 4;
   const int tiles = (R + 15) >> 4;
-  for (int t = wave; t < tiles; t += FT / 64) {
+  for (int t = wave; t < tiles; t += nw) {
     const int r0 = t * 16;
     const int arow = r0 + li;
     const bool rok = arow < R;
@@ -37,12 +41,20 @@ __device__ inline void wg_mm(const double* __restrict__ A, int R, int M, const d
         acc[r] = row < R ? O[row * CB + li] : 0.0;
       }
     }
-    for (int kc = 0; kc < M; kc += 64) {
-      double a[16];
+    double a[16], an[16];
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const int kk = kc + 4 * s + lk;
-        a[s] = (rok && kk < M) ? Ap[kk] : 0.0;
+    for (int s = 0; s < 16; ++s) {
+      const int kk = 4 * s + lk;
+      a[s] = (rok && kk < M) ? Ap[kk] : 0.0;
+    }
+    for (int kc = 0; kc < M; kc += 64) {
+      const bool more = kc + 64 < M;  // wave-uniform
+      if (more) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const int kk = kc + 64 + 4 * s + lk;
+          an[s] = (rok && kk < M) ? Ap[kk] : 0.0;
+        }
       }
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
@@ -51,6 +63,10 @@ __device__ inline void wg_mm(const double* __restrict__ A, int R, int M, const d
           const double b = kk < M ? V[kk * CB + li] : 0.0;
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b, acc, 0, 0, 0);
         }
+      }
+      if (more) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) a[s] = an[s];
       }
     }
 #pragma unroll
@@ -88,7 +104,7 @@ __device__ inline double wg_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
   __syncthreads();
-  const double t = (s[0] + s[1]) + (s[2] + s[3]);
+  const double t = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
   return t;
 }
@@ -124,8 +140,12 @@ __global__ __launch_bounds__(FT) void fused_pre_kernel(int K, int Rf, int64_t C,
     W[e] = (c0 + c < C) ? rho * wrow[r] * zf[g] - yf[g] : 0.0;
   }
   __syncthreads();
-  wg_mm<false>(Ft, K, Rf, W, T1);
-  if (has_rows) wg_mm<false>(HS, 2 * K, K, X, T2);
+  if (has_rows) {  // two independent products side by side
+    wg_mm<false>(Ft, K, Rf, W, T1, 0, 4);
+    wg_mm<false>(HS, 2 * K, K, X, T2, 4, 4);
+  } else {
+    wg_mm<false>(Ft, K, Rf, W, T1, 0, 8);
+  }
   __syncthreads();
   for (int e = threadIdx.x; e < K * CB; e += FT) T1[e] += sigma * X[e];  // rhsF
   __syncthreads();
@@ -141,7 +161,7 @@ __global__ __launch_bounds__(FT) void fused_pre_kernel(int K, int Rf, int64_t C,
       }
     }
   } else {
-    wg_mm<false>(Minv, K, K, T1, T2);
+    wg_mm<false>(Minv, K, K, T1, T2, 0, 8);
     __syncthreads();
     tile_store(T2, xt, K, C, c0);
   }
@@ -194,11 +214,11 @@ __global__ __launch_bounds__(FT) void fused_cg_init_kernel(int K, int64_t C, con
   tile_load(R, r0, K, C, c0);
   __syncthreads();
   tile_zero_global(G, K, C, c0);
-  wg_mm<true>(S0t, K, K, Gt, R);
+  wg_mm<true>(S0t, K, K, Gt, R, 0, 8);
   __syncthreads();
-  wg_mm<false>(Minv, K, K, R, Z);
+  wg_mm<false>(Minv, K, K, R, Z, 0, 8);
   __syncthreads();
-  wg_mm<false>(HS, 2 * K, K, Z, T2);
+  wg_mm<false>(HS, 2 * K, K, Z, T2, 0, 8);
   double dot = 0.0;
   for (int e = threadIdx.x; e < K * CB; e += FT) dot += R[e] * Z[e];
   dot = wg_sum(dot);  // (barrier inside: T2 complete afterwards)
@@ -228,7 +248,7 @@ __global__ __launch_bounds__(FT) void fused_cg_hp_kernel(int K, int64_t C, const
   tile_load(H, hpf, K, C, c0);
   __syncthreads();
   tile_zero_global(G, K, C, c0);
-  wg_mm<true>(S0t, K, K, Gt, H);
+  wg_mm<true>(S0t, K, K, Gt, H, 0, 8);
   __syncthreads();
   double dot = 0.0;
   for (int e = threadIdx.x; e < K * CB; e += FT) {
@@ -272,7 +292,7 @@ __global__ __launch_bounds__(FT) void fused_cg_step_kernel(int K, int64_t C, int
     R[e] = v;
   }
   __syncthreads();
-  wg_mm<false>(Minv, K, K, R, Z);
+  wg_mm<false>(Minv, K, K, R, Z, 0, 8);
   __syncthreads();
   double dot = 0.0;
   for (int e = threadIdx.x; e < K * CB; e += FT) dot += R[e] * Z[e];
@@ -306,7 +326,7 @@ __global__ __launch_bounds__(FT) void fused_cg_dir_kernel(int K, int64_t C, int 
     P[e] = v;
   }
   __syncthreads();
-  wg_mm<false>(HS, 2 * K, K, P, T2);
+  wg_mm<false>(HS, 2 * K, K, P, T2, 0, 8);
   __syncthreads();
   for (int e = threadIdx.x; e < K * CB; e += FT) {
     const int rr = e >> 4, c = e & 15;
@@ -332,8 +352,12 @@ __global__ __launch_bounds__(FT) void fused_post_kernel(int K, int Rf, int64_t C
   const int64_t c0 = (int64_t)blockIdx.x * CB;
   tile_load(X, xt, K, C, c0);
   __syncthreads();
-  wg_mm<false>(F, Rf, K, X, T);
-  if (has_rows) wg_mm<false>(S0, K, K, X, Qt);
+  if (has_rows) {
+    wg_mm<false>(F, Rf, K, X, T, 0, 6);
+    wg_mm<false>(S0, K, K, X, Qt, 6, 2);
+  } else {
+    wg_mm<false>(F, Rf, K, X, T, 0, 8);
+  }
   __syncthreads();
   for (int e = threadIdx.x; e < Rf * CB; e += FT) {
     const int r = e >> 4, c = e & 15;

@@ -141,6 +141,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # HBM traffic of that kernel from the committed PMC passes (profiles/README.md), same workload only
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pairwise_traffic.json")
+    if world == 1 and (N, K, D) == (1024, 50, 2) and os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f)["linearize"]["hbm_bytes"]
+
     # roofline of the dominant pairwise kernel (per rank: its own shard of rows)
     rows = pp.rows
     alg_bytes = rows * 8 * (D + 1) + 2 * N * K * D * 8  # 24 B/row (D=2) + the two trajectory arrays
@@ -170,7 +177,7 @@ def main():
         "roofline": {
             "kernel": "pair_pass_kernel<D,LINEARIZE> (scp_linearize_pairs)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "bytes_per_launch": alg_bytes, "rows_per_launch": rows, "avg_launch_ms": avg_ms,
+            "traffic": traffic, "bytes_per_launch": alg_bytes, "rows_per_launch": rows, "avg_launch_ms": avg_ms,
             "violations_pass_avg_ms": float(np.mean(viol_ms)) if viol_ms else None,
         },
     }

@@ -17,8 +17,8 @@ per-shard trajectories and compact working rows): total work is fixed -> "scalin
 The JSON line also carries
   roofline     : the pairwise linearisation kernel (HBM-write bound): algorithmic bytes per launch / its average
                  duration, measured live with HIP events around that launch on the stream it runs on;
-  cpu_baseline : the CPU oracle (oracle/, numpy restatement of the same algorithm = "port") timed on rank 0's host
-                 on a bounded sample of the same step.
+  cpu_baseline : the CPU oracle (oracle/scp_oracle_c.c, single-threaded C restatement of the same algorithm =
+                 "port") timed on rank 0's host on one complete step from the same input state (~30 s).
 """
 import argparse
 import json
@@ -34,10 +34,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 
 
 def cpu_baseline(N, K, D, h, T, R, space, p0, pf, margin, step_info, x0):
-    """Oracle (numpy port, 1 core) on a bounded sample of the same step; extrapolated with the step's own
-    ADMM-iteration and round counts (the oracle runs the identical algorithm, see tests/test_scp_gpu.py)."""
-    import numpy as np
-
+    """The C oracle (oracle/scp_oracle_c.c: single-threaded CPU statement of the same algorithm, pinned against
+    the numpy oracle and through it against the reference's golden vectors) runs ONE complete step -- the same
+    step as the GPU, from the same input state x0 -- on one host core."""
+    from oracle import c_oracle as co
     from oracle import qp_oracle as qo
     from oracle import scp_oracle as so
 
@@ -46,30 +46,22 @@ def cpu_baseline(N, K, D, h, T, R, space, p0, pf, margin, step_info, x0):
     except Exception:
         pass
     prob = so.make_problem(N, T, h, R, space, p0, pf)
-    pos, _ = so.kinematics(prob, x0)  # x0: the step's input state (QP#0 solution), same data as the GPU step
-    t = time.perf_counter()
-    eta, l_col, dist = so.linearize_pairs(prob, pos)
-    t_lin = time.perf_counter() - t
-    times = {}
-    for m in (1, 2, 8):  # m = 1 is an untimed warm-up of the allocator / caches
-        st = qo.Settings(max_iter=m, max_rounds=1, margin=margin, check_termination=10 ** 6)
-        t = time.perf_counter()
-        qo.admm_structured(prob, eta, l_col, dist, x0=x0, st=st)
-        times[m] = time.perf_counter() - t
-    # admm_structured ends every round with one full violation pass; t(m) = setup + m * t_it + t_viol
-    t_it = max((times[8] - times[2]) / 6.0, 1e-9)
-    t = time.perf_counter()
-    so.collision_apply(prob, eta, x0.ravel())
-    t_viol = time.perf_counter() - t
-    step_s = t_lin + step_info["rounds"] * t_viol + step_info["iter"] * t_it
+    t0 = time.perf_counter()
+    pos, _ = co.kinematics(prob, x0)
+    eta, l_col, dist = co.linearize_pairs(prob, pos)
+    t1 = time.perf_counter()
+    x1, info = co.admm(prob, eta, l_col, dist, x0, qo.Settings(max_iter=10000, margin=margin))
+    t2 = time.perf_counter()
+    step_s = t2 - t0
     return {
         "value": 1.0 / step_s,
         "unit": "SCP iterations/s",
         "cores": 1,
         "kind": "port",
-        "sample": (f"numpy oracle, 1 thread: full linearisation pass {t_lin:.2f}s + full violation pass {t_viol:.2f}s x "
-                   f"{step_info['rounds']} rounds + {t_it*1e3:.1f} ms/ADMM iteration (measured over 6 iterations) x "
-                   f"{step_info['iter']} iterations of the same step = {step_s:.1f}s per SCP iteration (extrapolated)"),
+        "sample": (f"C oracle, 1 thread, one complete step from the same state: linearisation of all rows {t1-t0:.2f}s + "
+                   f"joint QP {t2-t1:.2f}s ({info['iter']} ADMM iterations, {info['working_rows']} working rows, "
+                   f"{info['rounds']} rounds, status {info['status']}; the GPU step took {step_info['iter']} iterations, "
+                   f"{step_info['working_rows']} rows, {step_info['rounds']} rounds)"),
         "host_cpus": os.cpu_count(),
     }
 

@@ -567,7 +567,7 @@ extern "C" void scp_qp_default_settings(scp_qp_settings* s) {
   s->adaptive_rho = 1;
   s->adaptive_rho_interval = 25;
   s->adaptive_rho_tolerance = 5.0;
-  s->cg_iters = 3;
+  s->cg_iters = 1;
   s->use_mfma = 1;
 }
 

@@ -7,7 +7,7 @@
 // matrix cores -- v_mfma_f64_16x16x4_f64, one 16 x 16 output tile per wave and step, the A operand preloaded from
 // L2 in chunks of 16 k-steps so that a chain costs one memory latency, not one per step.  Kernel boundaries remain
 // only where the algorithm needs the whole grid: the two PCG inner products and the row gather/scatter.
-// An ADMM step with 3 PCG steps is 16 launches (45 on the generic path of scp_qp.hip, which stays as the fallback
+// An ADMM step with n PCG steps is 4n + 3 launches, 7 at the default n = 1 (15n + ... on the generic path of scp_qp.hip, which stays as the fallback
 // for K > 128 and as the use_mfma = 0/2 reference); the arithmetic is the same, statement by statement.
 #include "scp_qp_internal.h"
 
@@ -339,7 +339,14 @@ __global__ __launch_bounds__(FT) void fused_cg_dir_kernel(int K, int64_t C, int 
 }
 
 // ---- K_U: z~ = F x~ ; relaxation, projection, duals of the fixed rows ; x = alpha x~ + (1-alpha) x ; Q = S0 x~ ---
+// fold = 1: the LAST PCG step is applied here, x~ = xt + a p with a = rz / pHp (its residual update and the
+// preconditioner product would be dead work), saving one launch per ADMM step.
 __global__ __launch_bounds__(FT) void fused_post_kernel(int K, int Rf, int64_t C, double rho, double alpha, int has_rows,
+                                                         int fold, int nblk, int first, int slot,
+                                                         const double* __restrict__ scal,
+                                                         const double* __restrict__ part_rz,
+                                                         const double* __restrict__ part_php,
+                                                         const double* __restrict__ pdir,
                                                          const double* __restrict__ F, const double* __restrict__ S0,
                                                          const double* __restrict__ wrow, const double* __restrict__ xt,
                                                          const double* __restrict__ lf, const double* __restrict__ uf,
@@ -350,7 +357,18 @@ __global__ __launch_bounds__(FT) void fused_post_kernel(int K, int Rf, int64_t C
   double* T = X + K * CB;           // [Rf][16]
   double* Qt = T + Rf * CB;         // [K][16]
   const int64_t c0 = (int64_t)blockIdx.x * CB;
-  tile_load(X, xt, K, C, c0);
+  if (fold) {
+    const double rz = first ? sum_parts(part_rz, nblk) : scal[slot];
+    const double pHp = sum_parts(part_php, nblk);
+    const double a = (pHp > 0.0 && rz != 0.0) ? rz / pHp : 0.0;
+    for (int e = threadIdx.x; e < K * CB; e += FT) {
+      const int r = e >> 4, c = e & 15;
+      const int64_t g = (int64_t)r * C + c0 + c;
+      X[e] = (c0 + c < C) ? xt[g] + a * pdir[g] : 0.0;
+    }
+  } else {
+    tile_load(X, xt, K, C, c0);
+  }
   __syncthreads();
   if (has_rows) {
     wg_mm<false>(F, Rf, K, X, T, 0, 6);
@@ -422,6 +440,8 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
   double* Hp = d.HQ;       // H p slab
   double* part_rz = d.part;
   double* part_php = d.part + SCP_PART_CAP;
+  int fold = 0, fold_first = 0, fold_slot = SL_RZ0;
+  const double* fold_part = part_rz;
 
   hipLaunchKernelGGL(fused_pre_kernel, cgrid, cblock, (size_t)(4 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.sigma,
                      has_rows, d.Ft, d.HS, d.Minv, d.wrow, d.x, d.zf, d.yf, d.rhs, Q, d.xt, d.G);
@@ -438,7 +458,8 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
                        d.G, d.r, d.p, d.hpf, Q, part_rz);
     FUSED_LAUNCHED(qp);
     int slot = SL_RZ0;
-    for (int it = 0; it < qp->st.cg_iters; ++it) {
+    const int ncg = qp->st.cg_iters;
+    for (int it = 0; it < ncg; ++it) {
       if (qp->D == 2)
         hipLaunchKernelGGL((fused_rows_kernel<2, false>), rgrid, rblock, 0, s, qp->nW, C, qp->rho, d.w_k, d.w_i, d.w_j,
                            d.w_eta, d.zc, d.yc, Q, d.G);
@@ -449,6 +470,14 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
       hipLaunchKernelGGL(fused_cg_hp_kernel, cgrid, cblock, (size_t)(2 * K) * tile, s, K, C, d.S0t, d.G, d.hpf, d.p, Hp,
                          part_php);
       FUSED_LAUNCHED(qp);
+      ++*cg_count;
+      if (it + 1 == ncg) {  // the last step is folded into the post kernel
+        fold = 1;
+        fold_first = it == 0 ? 1 : 0;
+        fold_slot = slot;
+        fold_part = (it & 1) ? part_rz + SCP_PART_CAP / 2 : part_rz;
+        break;
+      }
       // the step kernel reads part_rz (first step) or scal[slot], writes the new partials to the OTHER half of
       // the rz array so that workgroups still summing the old partials are not disturbed
       double* part_new = (it & 1) ? part_rz : part_rz + SCP_PART_CAP / 2;
@@ -456,17 +485,15 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
       hipLaunchKernelGGL(fused_cg_step_kernel, cgrid, cblock, (size_t)(2 * K) * tile, s, K, C, nblk, it == 0 ? 1 : 0, slot,
                          d.Minv, d.scal, part_old, part_php, d.p, Hp, d.xt, d.r, d.zz, part_new);
       FUSED_LAUNCHED(qp);
-      ++*cg_count;
-      if (it + 1 < qp->st.cg_iters) {
-        hipLaunchKernelGGL(fused_cg_dir_kernel, cgrid, cblock, (size_t)(3 * K) * tile, s, K, C, nblk, slot, d.HS, d.scal,
-                           part_new, d.zz, d.p, d.hpf, Q);
-        FUSED_LAUNCHED(qp);
-        slot ^= 1;
-      }
+      hipLaunchKernelGGL(fused_cg_dir_kernel, cgrid, cblock, (size_t)(3 * K) * tile, s, K, C, nblk, slot, d.HS, d.scal,
+                         part_new, d.zz, d.p, d.hpf, Q);
+      FUSED_LAUNCHED(qp);
+      slot ^= 1;
     }
   }
   hipLaunchKernelGGL(fused_post_kernel, cgrid, cblock, (size_t)(2 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.alpha,
-                     has_rows, d.F, d.S0, d.wrow, d.xt, d.lf, d.uf, d.zf, d.yf, d.x, Q);
+                     has_rows, fold, nblk, fold_first, fold_slot, d.scal, fold_part, part_php, d.p, d.F, d.S0, d.wrow, d.xt,
+                     d.lf, d.uf, d.zf, d.yf, d.x, Q);
   FUSED_LAUNCHED(qp);
   if (has_rows) {
     if (qp->D == 2)

@@ -196,7 +196,7 @@ class Settings:
     adaptive_rho: bool = True
     adaptive_rho_interval: int = 25
     adaptive_rho_tolerance: float = 5.0
-    cg_iters: int = 3         # PCG iterations per ADMM step (fixed count; warm started)
+    cg_iters: int = 1         # PCG steps per ADMM step (fixed count; warm started at x)
     cg_tol: float = 0.0       # optional early exit: ||r||_2 <= cg_tol * ||rhs||_2
     margin: float = 0.5       # initial working set: rows with dist_prev - R < margin
     feas_tol: float = 1e-6    # a non-working row enters W when (A x)_r < l_r - feas_tol

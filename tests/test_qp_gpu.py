@@ -33,6 +33,7 @@ def ref_problem(n, seed, T=10.0, h=0.2, R=0.8):
 def make_qp(ctx, prob, **kw):
     from path_planning import _hip
 
+    kw.setdefault("cg_iters", 3)
     st = _hip.default_settings(**kw)
     qp = _hip.QP(ctx, prob.N, prob.K, prob.D, prob.h, st)
     space = np.concatenate([prob.pos_min, prob.pos_max])
@@ -71,6 +72,29 @@ def test_qp0_matches_oracle(ctx, n, seed, T, h, use_mfma):
                          max_iter=20000)
     assert r["status_val"] == 1
     np.testing.assert_allclose(x.ravel(), r["x"], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("cg,use_mfma", [(1, 1), (2, 1), (3, 2), (3, 0)])
+def test_collision_qp_paths_and_pcg_steps(ctx, cg, use_mfma):
+    """Default fused path with 1 and 2 PCG steps per ADMM step, and the generic MFMA / VALU paths: all follow
+    the oracle iterate for iterate."""
+    import torch
+
+    prob = ref_problem(10, 7, 10.0, 0.2)
+    x0, _, _ = qo.admm_structured(prob, st=oracle_settings(eps_abs=1e-8, eps_rel=1e-8))
+    pos, _ = so.kinematics(prob, x0)
+    eta, l_col, dist = so.linearize_pairs(prob, pos)
+    W = np.nonzero(dist - prob.R < 0.5)[0]
+    st = oracle_settings(max_iter=10000, max_rounds=1, cg_iters=cg)
+    xo, yo, io = qo.admm_structured(prob, eta, l_col, dist, x0=x0, st=st, rows0=W)
+    qp = make_qp(ctx, prob, max_iter=10000, cg_iters=cg, use_mfma=use_mfma)
+    qp.reset(ctx.tensor(x0))
+    qp.add_rows(torch.as_tensor(W, dtype=torch.int64, device=ctx.tdev), ctx.tensor(eta[W]), ctx.tensor(l_col[W]))
+    info = qp.solve()
+    assert info["status_val"] == io["status_val"] == 1 and info["iter"] == io["iter"]
+    assert info["cg_iters_total"] == cg * info["iter"]
+    np.testing.assert_allclose(qp.solution().cpu().numpy(), xo, rtol=0, atol=1e-8)
+    qp.close()
 
 
 @pytest.mark.parametrize("n,seed,T,h,margin", [(4, 1, 10.0, 0.5, 0.5), (10, 7, 10.0, 0.2, 0.5), (4, 1, 10.0, 0.5, 1e9)])

@@ -685,6 +685,7 @@ extern "C" int scp_qp_reset(scp_qp* qp, const double* x0) {
   SCP_HIP_CHECK(ctx, hipMemsetAsync(d.yf, 0, nf * sizeof(double), ctx->stream));
   qp->nW = 0;
   qp->rho = qp->st.rho;
+  qp->cg1_ready = false;
   QP_CHECK(build_kkt(qp));
   qp->reset_done = true;
   return SCP_OK;
@@ -706,6 +707,7 @@ extern "C" int scp_qp_add_rows(scp_qp* qp, int64_t n, const int64_t* rows, const
                      qp->nW, n, rows, w_eta, w_l, d.HQ + nx, d.w_row, d.w_k, d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc);
   QP_LAUNCHED(qp);
   qp->nW += n;
+  qp->cg1_ready = false;
   return SCP_OK;
 }
 
@@ -718,15 +720,18 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
   const scp_qp_settings& st = qp->st;
   memset(info, 0, sizeof(*info));
   info->status_val = -2;  // OSQP_MAX_ITER_REACHED
+  qp->cg1_ready = false;  // settings may have changed between calls
   SCP_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   int cg_total = 0, it = 0;
   double rp = INFINITY, rd = INFINITY;
   while (it < st.max_iter) {
     ++it;
-    if (fused) QP_CHECK(scp_qp_fused_iteration(qp, &cg_total));
+    if (fused && st.cg_iters == 1 && qp->nW > 0) QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total));
+    else if (fused) QP_CHECK(scp_qp_fused_iteration(qp, &cg_total));
     else QP_CHECK(admm_iteration(qp, &cg_total));
     if (it % st.check_termination == 0 || it >= st.max_iter) {
       QP_CHECK(residuals(qp));
+      qp->cg1_ready = false;  // residuals() used G and the Q slabs as scratch; rho may change below
       const double* hs = qp->h_scal;
       rp = hs[SL_RP];
       rd = hs[SL_RD];

@@ -2,7 +2,7 @@
 //
 // Every operation of an ADMM step except the working-row gather/scatter is local to a column c = (agent, axis):
 // the fixed rows, the K x K KKT block and the Toeplitz block S0 act along the time index only.
-// One workgroup (8 waves) therefore owns 16 columns, keeps their K-vectors as [rows][16] tiles in LDS and chains
+// One workgroup (16 waves) therefore owns 16 columns, keeps their K-vectors as [rows][16] tiles in LDS and chains
 // whole sequences of products  tile_out = A . tile_in  (A one of F^T, [H_f; S0], S0^T, H_f^{-1}, F) on the fp64
 // matrix cores -- v_mfma_f64_16x16x4_f64, one 16 x 16 output tile per wave and step, the A operand preloaded from
 // L2 in chunks of 16 k-steps so that a chain costs one memory latency, not one per step.  Kernel boundaries remain
@@ -14,7 +14,8 @@
 namespace {
 
 constexpr int CB = 16;         // columns per workgroup
-constexpr int FT = 512;        // threads per workgroup (8 waves)
+constexpr int FT = 1024;       // threads per workgroup (16 waves: one 16-row output tile per wave in most products)
+constexpr int NWV = FT / 64;
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // O[R][16] = (ACC ? O : 0) + A[R][M] . V[M][16];  A: global, row-major, leading dimension M;  V, O: distinct LDS tiles.
@@ -104,7 +105,9 @@ __device__ inline double wg_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
   __syncthreads();
-  const double t = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) t += s[w];
   __syncthreads();
   return t;
 }
@@ -141,10 +144,10 @@ __global__ __launch_bounds__(FT) void fused_pre_kernel(int K, int Rf, int64_t C,
   }
   __syncthreads();
   if (has_rows) {  // two independent products side by side
-    wg_mm<false>(Ft, K, Rf, W, T1, 0, 4);
-    wg_mm<false>(HS, 2 * K, K, X, T2, 4, 4);
-  } else {
     wg_mm<false>(Ft, K, Rf, W, T1, 0, 8);
+    wg_mm<false>(HS, 2 * K, K, X, T2, 8, NWV - 8);
+  } else {
+    wg_mm<false>(Ft, K, Rf, W, T1, 0, NWV);
   }
   __syncthreads();
   for (int e = threadIdx.x; e < K * CB; e += FT) T1[e] += sigma * X[e];  // rhsF
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(FT) void fused_pre_kernel(int K, int Rf, int64_t C,
       }
     }
   } else {
-    wg_mm<false>(Minv, K, K, T1, T2, 0, 8);
+    wg_mm<false>(Minv, K, K, T1, T2, 0, NWV);
     __syncthreads();
     tile_store(T2, xt, K, C, c0);
   }
@@ -214,11 +217,11 @@ __global__ __launch_bounds__(FT) void fused_cg_init_kernel(int K, int64_t C, con
   tile_load(R, r0, K, C, c0);
   __syncthreads();
   tile_zero_global(G, K, C, c0);
-  wg_mm<true>(S0t, K, K, Gt, R, 0, 8);
+  wg_mm<true>(S0t, K, K, Gt, R, 0, NWV);
   __syncthreads();
-  wg_mm<false>(Minv, K, K, R, Z, 0, 8);
+  wg_mm<false>(Minv, K, K, R, Z, 0, NWV);
   __syncthreads();
-  wg_mm<false>(HS, 2 * K, K, Z, T2, 0, 8);
+  wg_mm<false>(HS, 2 * K, K, Z, T2, 0, NWV);
   double dot = 0.0;
   for (int e = threadIdx.x; e < K * CB; e += FT) dot += R[e] * Z[e];
   dot = wg_sum(dot);  // (barrier inside: T2 complete afterwards)
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(FT) void fused_cg_hp_kernel(int K, int64_t C, const
   tile_load(H, hpf, K, C, c0);
   __syncthreads();
   tile_zero_global(G, K, C, c0);
-  wg_mm<true>(S0t, K, K, Gt, H, 0, 8);
+  wg_mm<true>(S0t, K, K, Gt, H, 0, NWV);
   __syncthreads();
   double dot = 0.0;
   for (int e = threadIdx.x; e < K * CB; e += FT) {
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(FT) void fused_cg_step_kernel(int K, int64_t C, int
     R[e] = v;
   }
   __syncthreads();
-  wg_mm<false>(Minv, K, K, R, Z, 0, 8);
+  wg_mm<false>(Minv, K, K, R, Z, 0, NWV);
   __syncthreads();
   double dot = 0.0;
   for (int e = threadIdx.x; e < K * CB; e += FT) dot += R[e] * Z[e];
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(FT) void fused_cg_dir_kernel(int K, int64_t C, int 
     P[e] = v;
   }
   __syncthreads();
-  wg_mm<false>(HS, 2 * K, K, P, T2, 0, 8);
+  wg_mm<false>(HS, 2 * K, K, P, T2, 0, NWV);
   __syncthreads();
   for (int e = threadIdx.x; e < K * CB; e += FT) {
     const int rr = e >> 4, c = e & 15;
@@ -371,10 +374,10 @@ __global__ __launch_bounds__(FT) void fused_post_kernel(int K, int Rf, int64_t C
   }
   __syncthreads();
   if (has_rows) {
-    wg_mm<false>(F, Rf, K, X, T, 0, 6);
-    wg_mm<false>(S0, K, K, X, Qt, 6, 2);
+    wg_mm<false>(F, Rf, K, X, T, 0, NWV - 3);
+    wg_mm<false>(S0, K, K, X, Qt, NWV - 3, 3);
   } else {
-    wg_mm<false>(F, Rf, K, X, T, 0, 8);
+    wg_mm<false>(F, Rf, K, X, T, 0, NWV);
   }
   __syncthreads();
   for (int e = threadIdx.x; e < Rf * CB; e += FT) {
@@ -420,6 +423,186 @@ __global__ __launch_bounds__(256) void fused_row_update_kernel(int64_t nW, int64
   const double zn = fmax(zh + y / rho, wl[n]);
   yc[n] = y + rho * (zh - zn);
   zc[n] = zn;
+}
+
+// =====================================================================================================
+// Single-PCG-step pipeline (settings.cg_iters == 1, the default): 4 launches per ADMM step.
+//
+//   x~ = x + a p,  p = Minv r,  r = rhs - H x,  a = (r.p) / (p.H p),   p.H p = p.(H_f p) + rho sum_rows (eta.dQp)^2
+//
+// so neither H p nor a second scatter is needed, and because x+ = alpha x~ + (1-alpha) x the slab Qx = S0 x follows
+// the recurrence Qx+ = alpha Qt + (1-alpha) Qx (refreshed exactly at every termination check).  Per step:
+//   colA     : W, rhsF = sigma x + F^T W, Hx = H_f x, r = rhsF - Hx + S0^T G, p = Minv r, [HpF; Qp] = [H_f; S0] p,
+//              partials r.p and p.HpF; G = 0
+//   rows_sq  : partials rho (eta.dQp)^2
+//   post1    : a; x~ = x + a p; z~ = F x~, Qt = S0 x~; fixed rows' z, y; x+; Qx+
+//   rows_ui  : collision rows' z, y from Qt; then G += eta (rho zc - yc - rho eta.dQx+)   (next step's scatter)
+// =====================================================================================================
+constexpr int SQ_BLOCKS = 128;
+
+__global__ __launch_bounds__(FT) void cg1_colA_kernel(int K, int Rf, int64_t C, double rho, double sigma,
+                                                       const double* __restrict__ Ft, const double* __restrict__ HS,
+                                                       const double* __restrict__ S0t, const double* __restrict__ Minv,
+                                                       const double* __restrict__ wrow, const double* __restrict__ x,
+                                                       const double* __restrict__ zf, const double* __restrict__ yf,
+                                                       double* __restrict__ G, double* __restrict__ p,
+                                                       double* __restrict__ Qp, double* __restrict__ part_rz,
+                                                       double* __restrict__ part_php) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* X = lds;                  // [K][16]    later: p tile
+  double* W = X + K * CB;           // [Rf][16]   later: [HpF ; Qp] (2K <= Rf rows)
+  double* T1 = W + Rf * CB;         // [K][16]    rhsF, then r
+  double* T2 = T1 + K * CB;         // [K][16]    H_f x
+  double* Gt = T2 + K * CB;         // [K][16]
+  const int64_t c0 = (int64_t)blockIdx.x * CB;
+  tile_load(X, x, K, C, c0);
+  tile_load(Gt, G, K, C, c0);
+  for (int e = threadIdx.x; e < Rf * CB; e += FT) {
+    const int r = e >> 4, c = e & 15;
+    const int64_t g = (int64_t)r * C + c0 + c;
+    W[e] = (c0 + c < C) ? rho * wrow[r] * zf[g] - yf[g] : 0.0;
+  }
+  __syncthreads();
+  tile_zero_global(G, K, C, c0);
+  wg_mm<false>(Ft, K, Rf, W, T1, 0, 8);            // F^T W
+  wg_mm<false>(HS, K, K, X, T2, 8, 4);             // H_f x   (first K rows of [H_f; S0])
+  __syncthreads();
+  for (int e = threadIdx.x; e < K * CB; e += FT) T1[e] = (T1[e] + sigma * X[e]) - T2[e];
+  __syncthreads();
+  wg_mm<true>(S0t, K, K, Gt, T1, 0, NWV);          // r = rhsF - Hx + S0^T G
+  __syncthreads();
+  wg_mm<false>(Minv, K, K, T1, X, 0, NWV);         // p = Minv r  (X tile reused)
+  __syncthreads();
+  wg_mm<false>(HS, 2 * K, K, X, W, 0, NWV);        // [HpF ; Qp]  (W tile reused)
+  double rz = 0.0;
+  for (int e = threadIdx.x; e < K * CB; e += FT) rz += T1[e] * X[e];
+  rz = wg_sum(rz);
+  double php = 0.0;
+  for (int e = threadIdx.x; e < K * CB; e += FT) php += X[e] * W[e];
+  php = wg_sum(php);
+  if (threadIdx.x == 0) {
+    part_rz[blockIdx.x] = rz;
+    part_php[blockIdx.x] = php;
+  }
+  for (int e = threadIdx.x; e < K * CB; e += FT) {
+    const int rr = e >> 4, c = e & 15;
+    if (c0 + c < C) {
+      const int64_t g = (int64_t)rr * C + c0 + c;
+      p[g] = X[e];
+      Qp[g] = W[K * CB + e];
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void cg1_rows_sq_kernel(int64_t nW, int64_t C, double rho, const int* __restrict__ wk,
+                                                           const int* __restrict__ wi, const int* __restrict__ wj,
+                                                           const double* __restrict__ weta,
+                                                           const double* __restrict__ Qp, double* __restrict__ part_sq) {
+  __shared__ double sw[4];
+  double acc = 0.0;
+  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nW; n += (int64_t)SQ_BLOCKS * 256) {
+    const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
+    const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
+    double ax = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) ax += weta[n * D + d] * (Qp[bi + d] - Qp[bj + d]);
+    acc += ax * ax;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part_sq[blockIdx.x] = rho * ((sw[0] + sw[1]) + (sw[2] + sw[3]));
+}
+
+__global__ __launch_bounds__(FT) void cg1_post_kernel(int K, int Rf, int64_t C, double rho, double alpha, int nblk,
+                                                       const double* __restrict__ part_rz,
+                                                       const double* __restrict__ part_php,
+                                                       const double* __restrict__ part_sq,
+                                                       const double* __restrict__ pdir, const double* __restrict__ F,
+                                                       const double* __restrict__ S0, const double* __restrict__ wrow,
+                                                       const double* __restrict__ lf, const double* __restrict__ uf,
+                                                       double* __restrict__ zf, double* __restrict__ yf,
+                                                       double* __restrict__ x, double* __restrict__ Qt,
+                                                       double* __restrict__ Qx) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* X = lds;                  // [K][16]   x~
+  double* T = X + K * CB;           // [Rf][16]  F x~
+  double* Q1 = T + Rf * CB;         // [K][16]   S0 x~
+  const int64_t c0 = (int64_t)blockIdx.x * CB;
+  const double rz = sum_parts(part_rz, nblk);
+  const double pHp = sum_parts(part_php, nblk) + sum_parts(part_sq, SQ_BLOCKS);
+  const double a = (pHp > 0.0 && rz != 0.0) ? rz / pHp : 0.0;
+  for (int e = threadIdx.x; e < K * CB; e += FT) {
+    const int r = e >> 4, c = e & 15;
+    const int64_t g = (int64_t)r * C + c0 + c;
+    X[e] = (c0 + c < C) ? x[g] + a * pdir[g] : 0.0;
+  }
+  __syncthreads();
+  wg_mm<false>(F, Rf, K, X, T, 0, NWV - 3);
+  wg_mm<false>(S0, K, K, X, Q1, NWV - 3, 3);
+  __syncthreads();
+  for (int e = threadIdx.x; e < Rf * CB; e += FT) {
+    const int r = e >> 4, c = e & 15;
+    if (c0 + c < C) {
+      const int64_t g = (int64_t)r * C + c0 + c;
+      const double rr = rho * wrow[r];
+      const double zh = alpha * T[e] + (1.0 - alpha) * zf[g];
+      const double y = yf[g];
+      const double zn = fmin(fmax(zh + y / rr, lf[g]), uf[g]);
+      yf[g] = y + rr * (zh - zn);
+      zf[g] = zn;
+    }
+  }
+  for (int e = threadIdx.x; e < K * CB; e += FT) {
+    const int r = e >> 4, c = e & 15;
+    if (c0 + c < C) {
+      const int64_t g = (int64_t)r * C + c0 + c;
+      x[g] = alpha * X[e] + (1.0 - alpha) * x[g];
+      Qt[g] = Q1[e];
+      Qx[g] = alpha * Q1[e] + (1.0 - alpha) * Qx[g];
+    }
+  }
+}
+
+// update = 1: z, y of the collision rows from Qt (= S0 x~); then the scatter of the NEXT x-update's right-hand
+// side and H x:  G += eta (rho zc - yc - rho eta.dQx)
+template <int D>
+__global__ __launch_bounds__(256) void cg1_rows_ui_kernel(int64_t nW, int64_t C, double rho, double alpha, int update,
+                                                           const int* __restrict__ wk, const int* __restrict__ wi,
+                                                           const int* __restrict__ wj, const double* __restrict__ weta,
+                                                           const double* __restrict__ wl, const double* __restrict__ Qt,
+                                                           const double* __restrict__ Qx, double* __restrict__ zc,
+                                                           double* __restrict__ yc, double* __restrict__ G) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= nW) return;
+  const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
+  const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
+  double e[D], tc = 0.0, ax = 0.0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    e[d] = weta[n * D + d];
+    ax += e[d] * (Qx[bi + d] - Qx[bj + d]);
+  }
+  double z = zc[n], y = yc[n];
+  if (update) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) tc += e[d] * (Qt[bi + d] - Qt[bj + d]);
+    const double zh = alpha * tc + (1.0 - alpha) * z;
+    const double zn = fmax(zh + y / rho, wl[n]);
+    y = y + rho * (zh - zn);
+    z = zn;
+    yc[n] = y;
+    zc[n] = z;
+  }
+  const double g = (rho * z - y) - rho * ax;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const double c = e[d] * g;
+    atomicAdd(G + bi + d, c);
+    atomicAdd(G + bj + d, -c);
+  }
 }
 
 #define FUSED_LAUNCHED(qp) SCP_HIP_CHECK((qp)->ctx, hipGetLastError())
@@ -504,5 +687,70 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
                          d.w_j, d.w_eta, d.w_l, Q, d.zc, d.yc);
     FUSED_LAUNCHED(qp);
   }
+  return SCP_OK;
+}
+
+// Bring the single-step pipeline's carried state in line with (x, zc, yc, rho): Qx = S0 x exactly, G = scatter.
+int scp_qp_cg1_prepare(scp_qp* qp) {
+  const QpDev& d = qp->d;
+  hipStream_t s = qp->ctx->stream;
+  const int K = qp->K;
+  const int64_t C = qp->C, nx = (int64_t)K * C;
+  double* Qx = d.HQ + nx;
+  int rc = scp_launch_gemm(qp->ctx, 1, K, K, (int)C, 1.0, d.S0, d.x, 0.0, Qx);
+  if (rc) return rc;
+  SCP_HIP_CHECK(qp->ctx, hipMemsetAsync(d.G, 0, nx * sizeof(double), s));
+  const dim3 rgrid((unsigned)((qp->nW + 255) / 256)), rblock(256);
+  if (qp->D == 2)
+    hipLaunchKernelGGL(cg1_rows_ui_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, qp->rho, qp->st.alpha, 0, d.w_k, d.w_i,
+                       d.w_j, d.w_eta, d.w_l, d.HQ, Qx, d.zc, d.yc, d.G);
+  else
+    hipLaunchKernelGGL(cg1_rows_ui_kernel<3>, rgrid, rblock, 0, s, qp->nW, C, qp->rho, qp->st.alpha, 0, d.w_k, d.w_i,
+                       d.w_j, d.w_eta, d.w_l, d.HQ, Qx, d.zc, d.yc, d.G);
+  FUSED_LAUNCHED(qp);
+  qp->cg1_ready = true;
+  return SCP_OK;
+}
+
+int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count) {
+  const QpDev& d = qp->d;
+  hipStream_t s = qp->ctx->stream;
+  const int K = qp->K, Rf = qp->Rf;
+  const int64_t C = qp->C, nx = (int64_t)K * C;
+  const int nblk = (int)((C + CB - 1) / CB);
+  const dim3 cgrid(nblk), cblock(FT);
+  const dim3 rgrid((unsigned)((qp->nW + 255) / 256)), rblock(256);
+  const size_t tile = (size_t)CB * sizeof(double);
+  double* Qx = d.HQ + nx;   // S0 x (carried)
+  double* Qt = d.HQ;        // S0 x~
+  double* Qp = d.hpf;       // S0 p
+  double* part_rz = d.part;
+  double* part_php = d.part + SCP_PART_CAP;
+  double* part_sq = d.part + SCP_PART_CAP / 2;
+  if (!qp->cg1_ready) {
+    int rc = scp_qp_cg1_prepare(qp);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(cg1_colA_kernel, cgrid, cblock, (size_t)(4 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.sigma, d.Ft,
+                     d.HS, d.S0t, d.Minv, d.wrow, d.x, d.zf, d.yf, d.G, d.p, Qp, part_rz, part_php);
+  FUSED_LAUNCHED(qp);
+  if (qp->D == 2)
+    hipLaunchKernelGGL(cg1_rows_sq_kernel<2>, dim3(SQ_BLOCKS), rblock, 0, s, qp->nW, C, qp->rho, d.w_k, d.w_i, d.w_j,
+                       d.w_eta, Qp, part_sq);
+  else
+    hipLaunchKernelGGL(cg1_rows_sq_kernel<3>, dim3(SQ_BLOCKS), rblock, 0, s, qp->nW, C, qp->rho, d.w_k, d.w_i, d.w_j,
+                       d.w_eta, Qp, part_sq);
+  FUSED_LAUNCHED(qp);
+  hipLaunchKernelGGL(cg1_post_kernel, cgrid, cblock, (size_t)(2 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.alpha, nblk,
+                     part_rz, part_php, part_sq, d.p, d.F, d.S0, d.wrow, d.lf, d.uf, d.zf, d.yf, d.x, Qt, Qx);
+  FUSED_LAUNCHED(qp);
+  if (qp->D == 2)
+    hipLaunchKernelGGL(cg1_rows_ui_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, qp->rho, qp->st.alpha, 1, d.w_k, d.w_i, d.w_j,
+                       d.w_eta, d.w_l, Qt, Qx, d.zc, d.yc, d.G);
+  else
+    hipLaunchKernelGGL(cg1_rows_ui_kernel<3>, rgrid, rblock, 0, s, qp->nW, C, qp->rho, qp->st.alpha, 1, d.w_k, d.w_i, d.w_j,
+                       d.w_eta, d.w_l, Qt, Qx, d.zc, d.yc, d.G);
+  FUSED_LAUNCHED(qp);
+  ++*cg_count;
   return SCP_OK;
 }

@@ -36,6 +36,7 @@ struct scp_qp {
   scp_qp_settings st;
   int64_t row_cap, nW;
   bool problem_set, reset_done;
+  bool cg1_ready;  // carried state (Qx, G) of the single-step pipeline matches (x, zc, yc, rho)
   double rho;
   QpDev d;
   double* h_scal;  // pinned
@@ -47,3 +48,5 @@ struct scp_qp {
 constexpr int SCP_FUSED_MAX_K = 64;   // (4K + 4K-1) * 128 B of LDS tiles must stay below 64 KiB
 constexpr int SCP_PART_CAP = 4096;  // capacity of each partial-sum array (column blocks of the fused path)
 int scp_qp_fused_iteration(scp_qp* qp, int* cg_count);
+// single-PCG-step pipeline (cg_iters == 1 and a non-empty working set): 4 launches per ADMM step
+int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count);

@@ -32,10 +32,17 @@ class Shard:
         return self.N * r // self.world, self.N * (r + 1) // self.world
 
     # ---- collectives ---------------------------------------------------------------------------
+    def _host_staged(self, tensor):
+        """gloo moves host memory: CUDA tensors are staged through the host (rehearsals on one GPU); with RCCL
+        ("nccl") the collectives run on the device buffers directly."""
+        return tensor.is_cuda and dist.get_backend(self.group) == "gloo"
+
     def allgather_positions(self, local):
         """local: (n_local, K, D) trajectories of this rank's agents -> (N, K, D) on every rank."""
         if self.world == 1:
             return local
+        if self._host_staged(local):
+            return self.allgather_positions(local.cpu()).to(local.device)
         counts = [self.agent_range(r)[1] - self.agent_range(r)[0] for r in range(self.world)]
         if len(set(counts)) == 1:
             out = torch.empty((self.N,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -52,6 +59,10 @@ class Shard:
         """Concatenate every rank's compact rows (ids (n,), eta (n, D), l (n,)) in rank order."""
         if self.world == 1:
             return rows, w_eta, w_l
+        if self._host_staged(rows):
+            dev = rows.device
+            r, e, l = self.allgather_rows(rows.cpu(), w_eta.cpu(), w_l.cpu())
+            return r.to(dev), e.to(dev), l.to(dev)
         n = torch.tensor([rows.numel()], dtype=torch.int64, device=rows.device)
         counts = [torch.zeros_like(n) for _ in range(self.world)]
         dist.all_gather(counts, n, group=self.group)
@@ -72,7 +83,12 @@ class Shard:
 
     def broadcast(self, tensor, src=0):
         if self.world > 1:
-            dist.broadcast(tensor, src=src, group=self.group)
+            if self._host_staged(tensor):
+                host = tensor.cpu()
+                dist.broadcast(host, src=src, group=self.group)
+                tensor.copy_(host)
+            else:
+                dist.broadcast(tensor, src=src, group=self.group)
         return tensor
 
     def all_min(self, value: float) -> float:

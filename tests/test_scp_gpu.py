@@ -140,3 +140,46 @@ def test_plots_headless(tmp_path):
     s.visualize_trajectories(save_path=str(tmp_path / "t.pdf"))
     s.visualize_time_snapshots(num_snapshots=3, save_path=str(tmp_path / "s.pdf"))
     assert (tmp_path / "t.pdf").stat().st_size > 0 and (tmp_path / "s.pdf").stat().st_size > 0
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    import os
+    import sys
+
+    import torch.distributed as dist
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "ba-path-planning_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from path_planning.scenarios.position_generator import generate_grid_swap
+    from path_planning.solvers.scp import SCP
+
+    p0, pf, space = generate_grid_swap(40, seed=11)
+    s = SCP(40, 10.0, 0.2, 0.8, space, verbose=False, device=0, rank=rank, world_size=world)
+    s.set_initial_states(p0)
+    s.set_final_states(pf)
+    traj = s.generate_trajectories(max_iterations=3)
+    np.save(os.path.join(out_dir, f"pos_{rank}.npy"), traj["positions"])
+    np.save(os.path.join(out_dir, f"its_{rank}.npy"), np.array([i["iter"] for i in s.last_info["iterations"]]))
+    dist.destroy_process_group()
+
+
+def test_scp_two_ranks_share_one_gpu(tmp_path):
+    """The N>1 path end to end on the GPU: 2 ranks (both on cuda:0, gloo standing in for RCCL) shard the pair
+    ranges and the agents, exchange trajectories and compact rows, and reproduce the single-rank solve."""
+    import os
+
+    import torch.multiprocessing as mp
+    from path_planning.scenarios.position_generator import generate_grid_swap
+
+    port = 29600 + os.getpid() % 300
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "pos_0.npy"), np.load(tmp_path / "pos_1.npy")
+    np.testing.assert_array_equal(a, b)
+    p0, pf, space = generate_grid_swap(40, seed=11)
+    s, traj = solve_gpu(40, 10.0, 0.2, 0.8, space, p0, pf, max_iterations=3)
+    assert [i["iter"] for i in s.last_info["iterations"]] == np.load(tmp_path / "its_0.npy").tolist()
+    np.testing.assert_allclose(a, traj["positions"], rtol=0, atol=1e-8)

@@ -418,11 +418,12 @@ int row_scatter(scp_qp* qp, const double* Q) {
   const QpDev& d = qp->d;
   hipStream_t s = qp->ctx->stream;
   SCP_HIP_CHECK(qp->ctx, hipMemsetAsync(d.G, 0, (size_t)qp->K * qp->C * sizeof(double), s));
+  const double rho_c = qp->rho * qp->st.rho_col_scale;
   if (qp->D == 2)
-    hipLaunchKernelGGL((row_scatter_kernel<2, MODE>), grid1(qp->nW), dim3(256), 0, s, qp->nW, qp->C, qp->rho, d.w_k,
+    hipLaunchKernelGGL((row_scatter_kernel<2, MODE>), grid1(qp->nW), dim3(256), 0, s, qp->nW, qp->C, rho_c, d.w_k,
                        d.w_i, d.w_j, d.w_eta, d.zc, d.yc, Q, d.G);
   else
-    hipLaunchKernelGGL((row_scatter_kernel<3, MODE>), grid1(qp->nW), dim3(256), 0, s, qp->nW, qp->C, qp->rho, d.w_k,
+    hipLaunchKernelGGL((row_scatter_kernel<3, MODE>), grid1(qp->nW), dim3(256), 0, s, qp->nW, qp->C, rho_c, d.w_k,
                        d.w_i, d.w_j, d.w_eta, d.zc, d.yc, Q, d.G);
   QP_LAUNCHED(qp);
   return SCP_OK;
@@ -503,10 +504,12 @@ int admm_iteration(scp_qp* qp, int* cg_count) {
   if (qp->nW > 0) {
     QP_CHECK(gemm(qp, K, K, 1.0, d.S0, d.xt, 0.0, d.HQ + nx));
     if (qp->D == 2)
-      hipLaunchKernelGGL(admm_row_update_kernel<2>, grid1(qp->nW), dim3(256), 0, s, qp->nW, C, qp->rho, qp->st.alpha,
+      hipLaunchKernelGGL(admm_row_update_kernel<2>, grid1(qp->nW), dim3(256), 0, s, qp->nW, C,
+                         qp->rho * qp->st.rho_col_scale, qp->st.alpha,
                          d.w_k, d.w_i, d.w_j, d.w_eta, d.w_l, d.HQ + nx, d.zc, d.yc);
     else
-      hipLaunchKernelGGL(admm_row_update_kernel<3>, grid1(qp->nW), dim3(256), 0, s, qp->nW, C, qp->rho, qp->st.alpha,
+      hipLaunchKernelGGL(admm_row_update_kernel<3>, grid1(qp->nW), dim3(256), 0, s, qp->nW, C,
+                         qp->rho * qp->st.rho_col_scale, qp->st.alpha,
                          d.w_k, d.w_i, d.w_j, d.w_eta, d.w_l, d.HQ + nx, d.zc, d.yc);
     QP_LAUNCHED(qp);
   }
@@ -569,6 +572,7 @@ extern "C" void scp_qp_default_settings(scp_qp_settings* s) {
   s->adaptive_rho_tolerance = 5.0;
   s->cg_iters = 1;
   s->use_mfma = 1;
+  s->rho_col_scale = 10.0;
 }
 
 extern "C" size_t scp_qp_workspace_bytes(int N, int K, int D, int64_t row_capacity) {
@@ -578,7 +582,8 @@ extern "C" size_t scp_qp_workspace_bytes(int N, int K, int D, int64_t row_capaci
 }
 
 static int check_settings(scp_ctx* ctx, const scp_qp_settings* s) {
-  SCP_REQUIRE(ctx, s->rho > 0 && s->sigma > 0 && s->alpha > 0 && s->alpha < 2 && s->rho_eq_scale > 0,
+  SCP_REQUIRE(ctx, s->rho > 0 && s->sigma > 0 && s->alpha > 0 && s->alpha < 2 && s->rho_eq_scale > 0 &&
+                       s->rho_col_scale > 0,
               "qp settings: rho/sigma/alpha out of range");
   SCP_REQUIRE(ctx, s->max_iter > 0 && s->check_termination > 0 && s->cg_iters >= 0, "qp settings: bad iteration counts");
   return SCP_OK;

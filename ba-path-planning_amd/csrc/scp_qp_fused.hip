@@ -616,6 +616,7 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
   const int64_t C = qp->C, nx = (int64_t)K * C;
   const int nblk = (int)((C + CB - 1) / CB);
   const int has_rows = qp->nW > 0 ? 1 : 0;
+  const double rho_c = qp->rho * qp->st.rho_col_scale;
   const dim3 cgrid(nblk), cblock(FT);
   const dim3 rgrid((unsigned)((qp->nW + 255) / 256)), rblock(256);
   const size_t tile = (size_t)CB * sizeof(double);
@@ -631,10 +632,10 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
   FUSED_LAUNCHED(qp);
   if (has_rows) {
     if (qp->D == 2)
-      hipLaunchKernelGGL((fused_rows_kernel<2, true>), rgrid, rblock, 0, s, qp->nW, C, qp->rho, d.w_k, d.w_i, d.w_j,
+      hipLaunchKernelGGL((fused_rows_kernel<2, true>), rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
                          d.w_eta, d.zc, d.yc, Q, d.G);
     else
-      hipLaunchKernelGGL((fused_rows_kernel<3, true>), rgrid, rblock, 0, s, qp->nW, C, qp->rho, d.w_k, d.w_i, d.w_j,
+      hipLaunchKernelGGL((fused_rows_kernel<3, true>), rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
                          d.w_eta, d.zc, d.yc, Q, d.G);
     FUSED_LAUNCHED(qp);
     hipLaunchKernelGGL(fused_cg_init_kernel, cgrid, cblock, (size_t)(5 * K) * tile, s, K, C, d.S0t, d.Minv, d.HS, d.rhs,
@@ -644,10 +645,10 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
     const int ncg = qp->st.cg_iters;
     for (int it = 0; it < ncg; ++it) {
       if (qp->D == 2)
-        hipLaunchKernelGGL((fused_rows_kernel<2, false>), rgrid, rblock, 0, s, qp->nW, C, qp->rho, d.w_k, d.w_i, d.w_j,
+        hipLaunchKernelGGL((fused_rows_kernel<2, false>), rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
                            d.w_eta, d.zc, d.yc, Q, d.G);
       else
-        hipLaunchKernelGGL((fused_rows_kernel<3, false>), rgrid, rblock, 0, s, qp->nW, C, qp->rho, d.w_k, d.w_i, d.w_j,
+        hipLaunchKernelGGL((fused_rows_kernel<3, false>), rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
                            d.w_eta, d.zc, d.yc, Q, d.G);
       FUSED_LAUNCHED(qp);
       hipLaunchKernelGGL(fused_cg_hp_kernel, cgrid, cblock, (size_t)(2 * K) * tile, s, K, C, d.S0t, d.G, d.hpf, d.p, Hp,
@@ -680,10 +681,10 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
   FUSED_LAUNCHED(qp);
   if (has_rows) {
     if (qp->D == 2)
-      hipLaunchKernelGGL(fused_row_update_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, qp->rho, qp->st.alpha, d.w_k, d.w_i,
+      hipLaunchKernelGGL(fused_row_update_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, rho_c, qp->st.alpha, d.w_k, d.w_i,
                          d.w_j, d.w_eta, d.w_l, Q, d.zc, d.yc);
     else
-      hipLaunchKernelGGL(fused_row_update_kernel<3>, rgrid, rblock, 0, s, qp->nW, C, qp->rho, qp->st.alpha, d.w_k, d.w_i,
+      hipLaunchKernelGGL(fused_row_update_kernel<3>, rgrid, rblock, 0, s, qp->nW, C, rho_c, qp->st.alpha, d.w_k, d.w_i,
                          d.w_j, d.w_eta, d.w_l, Q, d.zc, d.yc);
     FUSED_LAUNCHED(qp);
   }
@@ -697,15 +698,16 @@ int scp_qp_cg1_prepare(scp_qp* qp) {
   const int K = qp->K;
   const int64_t C = qp->C, nx = (int64_t)K * C;
   double* Qx = d.HQ + nx;
+  const double rho_c = qp->rho * qp->st.rho_col_scale;
   int rc = scp_launch_gemm(qp->ctx, 1, K, K, (int)C, 1.0, d.S0, d.x, 0.0, Qx);
   if (rc) return rc;
   SCP_HIP_CHECK(qp->ctx, hipMemsetAsync(d.G, 0, nx * sizeof(double), s));
   const dim3 rgrid((unsigned)((qp->nW + 255) / 256)), rblock(256);
   if (qp->D == 2)
-    hipLaunchKernelGGL(cg1_rows_ui_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, qp->rho, qp->st.alpha, 0, d.w_k, d.w_i,
+    hipLaunchKernelGGL(cg1_rows_ui_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, rho_c, qp->st.alpha, 0, d.w_k, d.w_i,
                        d.w_j, d.w_eta, d.w_l, d.HQ, Qx, d.zc, d.yc, d.G);
   else
-    hipLaunchKernelGGL(cg1_rows_ui_kernel<3>, rgrid, rblock, 0, s, qp->nW, C, qp->rho, qp->st.alpha, 0, d.w_k, d.w_i,
+    hipLaunchKernelGGL(cg1_rows_ui_kernel<3>, rgrid, rblock, 0, s, qp->nW, C, rho_c, qp->st.alpha, 0, d.w_k, d.w_i,
                        d.w_j, d.w_eta, d.w_l, d.HQ, Qx, d.zc, d.yc, d.G);
   FUSED_LAUNCHED(qp);
   qp->cg1_ready = true;
@@ -727,6 +729,7 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count) {
   double* part_rz = d.part;
   double* part_php = d.part + SCP_PART_CAP;
   double* part_sq = d.part + SCP_PART_CAP / 2;
+  const double rho_c = qp->rho * qp->st.rho_col_scale;
   if (!qp->cg1_ready) {
     int rc = scp_qp_cg1_prepare(qp);
     if (rc) return rc;
@@ -735,20 +738,20 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count) {
                      d.HS, d.S0t, d.Minv, d.wrow, d.x, d.zf, d.yf, d.G, d.p, Qp, part_rz, part_php);
   FUSED_LAUNCHED(qp);
   if (qp->D == 2)
-    hipLaunchKernelGGL(cg1_rows_sq_kernel<2>, dim3(SQ_BLOCKS), rblock, 0, s, qp->nW, C, qp->rho, d.w_k, d.w_i, d.w_j,
+    hipLaunchKernelGGL(cg1_rows_sq_kernel<2>, dim3(SQ_BLOCKS), rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
                        d.w_eta, Qp, part_sq);
   else
-    hipLaunchKernelGGL(cg1_rows_sq_kernel<3>, dim3(SQ_BLOCKS), rblock, 0, s, qp->nW, C, qp->rho, d.w_k, d.w_i, d.w_j,
+    hipLaunchKernelGGL(cg1_rows_sq_kernel<3>, dim3(SQ_BLOCKS), rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
                        d.w_eta, Qp, part_sq);
   FUSED_LAUNCHED(qp);
   hipLaunchKernelGGL(cg1_post_kernel, cgrid, cblock, (size_t)(2 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.alpha, nblk,
                      part_rz, part_php, part_sq, d.p, d.F, d.S0, d.wrow, d.lf, d.uf, d.zf, d.yf, d.x, Qt, Qx);
   FUSED_LAUNCHED(qp);
   if (qp->D == 2)
-    hipLaunchKernelGGL(cg1_rows_ui_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, qp->rho, qp->st.alpha, 1, d.w_k, d.w_i, d.w_j,
+    hipLaunchKernelGGL(cg1_rows_ui_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, rho_c, qp->st.alpha, 1, d.w_k, d.w_i, d.w_j,
                        d.w_eta, d.w_l, Qt, Qx, d.zc, d.yc, d.G);
   else
-    hipLaunchKernelGGL(cg1_rows_ui_kernel<3>, rgrid, rblock, 0, s, qp->nW, C, qp->rho, qp->st.alpha, 1, d.w_k, d.w_i, d.w_j,
+    hipLaunchKernelGGL(cg1_rows_ui_kernel<3>, rgrid, rblock, 0, s, qp->nW, C, rho_c, qp->st.alpha, 1, d.w_k, d.w_i, d.w_j,
                        d.w_eta, d.w_l, Qt, Qx, d.zc, d.yc, d.G);
   FUSED_LAUNCHED(qp);
   ++*cg_count;

@@ -201,6 +201,7 @@ class Settings:
     margin: float = 0.5       # initial working set: rows with dist_prev - R < margin
     feas_tol: float = 1e-6    # a non-working row enters W when (A x)_r < l_r - feas_tol
     max_rounds: int = 20      # constraint-generation rounds
+    rho_col_scale: float = 10.0  # rho of the collision rows = rho * rho_col_scale
 
 
 class FixedOps:
@@ -313,13 +314,14 @@ def admm_structured(prob: so.Problem, eta=None, l_col=None, dist=None, x0=None, 
             rk = lambda r: r[None, :, None]
             # rhs = sigma x + A^T (rho z - y)
             rhs = st.sigma * x + ops.apply_T(rho * zj - yj, rho * za - ya, rk(rvv) * zv - yv, rk(rpp) * zp - yp)
+            rho_c = rho * st.rho_col_scale
             if W.size:
-                rhs = rhs + col_apply_T(rho * zc - yc, wk, wi, wj_, we)
+                rhs = rhs + col_apply_T(rho_c * zc - yc, wk, wi, wj_, we)
 
             def Hmul(p):
                 out = np.einsum("km,imd->ikd", Hf, p)
                 if W.size:
-                    out = out + col_apply_T(rho * col_apply(p, wk, wi, wj_, we), wk, wi, wj_, we)
+                    out = out + col_apply_T(rho_c * col_apply(p, wk, wi, wj_, we), wk, wi, wj_, we)
                 return out
 
             if W.size:
@@ -363,7 +365,7 @@ def admm_structured(prob: so.Problem, eta=None, l_col=None, dist=None, x0=None, 
             zp, yp = upd(tp, zp, yp, rk(rpp), lp, up)
             if W.size:
                 tc = col_apply(xt, wk, wi, wj_, we)
-                zc, yc = upd(tc, zc, yc, rho, wl, np.inf)
+                zc, yc = upd(tc, zc, yc, rho_c, wl, np.inf)
             x = x_new
 
             check = (it % st.check_termination == 0) or total_it >= st.max_iter

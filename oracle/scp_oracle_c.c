@@ -32,6 +32,7 @@ typedef struct {
   int cg_iters;
   double margin, feas_tol;
   int max_rounds;
+  double rho_col_scale; /* rho of the collision rows = rho * rho_col_scale */
 } oc_settings;
 
 typedef struct {
@@ -351,6 +352,7 @@ int oc_admm(const oc_problem* P, const double* eta, const double* l_col, const d
     while (total_it < st->max_iter) {
       ++it;
       ++total_it;
+      const double rhoc = rho * st->rho_col_scale;
       /* rhs = sigma x + F^T (R z - y) + A_W^T (rho zc - yc) */
       for (int c = 0; c < C; ++c) {
         const size_t o = (size_t)c * K;
@@ -365,14 +367,14 @@ int oc_admm(const oc_problem* P, const double* eta, const double* l_col, const d
         for (int k = 0; k < K; ++k) rhs[o + k] += st->sigma * x[o + k];
       }
       if (nW > 0) {
-        for (int64_t n = 0; n < nW; ++n) gc[n] = rho * zc[n] - yc[n];
+        for (int64_t n = 0; n < nW; ++n) gc[n] = rhoc * zc[n] - yc[n];
         rows_apply_T_add(&R, gc, rhs);
         /* PCG, preconditioner Minv, warm start xt = x */
 #define HMUL(v, out)                                                              \
   do {                                                                            \
     dense_apply(K, C, Hf, (v), (out));                                            \
     rows_apply(&R, (v), tc);                                                      \
-    for (int64_t n_ = 0; n_ < nW; ++n_) tc[n_] *= rho;                            \
+    for (int64_t n_ = 0; n_ < nW; ++n_) tc[n_] *= rhoc;                           \
     rows_apply_T_add(&R, tc, (out));                                              \
   } while (0)
         memcpy(xt, x, sizeof(double) * nx);
@@ -435,8 +437,8 @@ int oc_admm(const oc_problem* P, const double* eta, const double* l_col, const d
         rows_apply(&R, xt, tc);
         for (int64_t n = 0; n < nW; ++n) {
           const double zh = al * tc[n] + (1 - al) * zc[n];
-          const double zn = dmax(zh + yc[n] / rho, wl[n]);
-          yc[n] += rho * (zh - zn);
+          const double zn = dmax(zh + yc[n] / rhoc, wl[n]);
+          yc[n] += rhoc * (zh - zn);
           zc[n] = zn;
         }
       }

@@ -85,7 +85,7 @@ def test_scp_3d_z0_metamorphic():
     z = np.zeros((6, 1))
     s3, t3 = solve_gpu(6, 10.0, 0.5, 0.8, [0, 0, -5, 20, 20, 5], np.hstack([p0, z]), np.hstack([pf, z]), dim=3)
     assert s2.last_info["n_iterations"] == s3.last_info["n_iterations"]
-    np.testing.assert_allclose(t3["positions"][:, :, :2], t2["positions"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(t3["positions"][:, :, :2], t2["positions"], rtol=0, atol=TOL)  # summation order differs (C = 12 vs 18 columns)
     assert np.abs(t3["positions"][:, :, 2]).max() < 1e-12
 
 

@@ -349,7 +349,7 @@ __device__ inline void atomic_max_double(double* addr, double v) {
 }
 
 constexpr int PAIR_THREADS = 256;
-constexpr int PAIR_STEPS = 8;                              // steps per thread, 2 adjacent rows per step
+constexpr int PAIR_STEPS = 16;                             // steps per thread, 2 adjacent rows per step
 constexpr int PAIR_UNROLL = 4;                             // independent steps in flight per thread
 constexpr int PAIR_ROWS = PAIR_THREADS * PAIR_STEPS * 2;   // rows (= pairs at one k) per workgroup
 

@@ -141,6 +141,9 @@ def build_parser():
     p.add_argument("--seed", type=int, default=None)
     p.add_argument("--results-dir", default=None)
     p.add_argument("--max-iterations", type=int, default=None)
+    p.add_argument("--streams", type=int, default=1,
+                   help="solve this many scenarios concurrently on one GPU, each on its own HIP stream (a solve of "
+                        "~100 agents is latency bound and leaves the GPU mostly idle)")
     return p
 
 
@@ -177,16 +180,44 @@ def main(argv=None):
         print(f"Max SCP iterations: {cfg['max_iterations']}")
         print()
 
-    runs = []
-    for N, trial in jobs_for_rank(cfg, rank, world):
+    def one_job(job):
+        N, trial = job
         seed = trial_seed(cfg, N, trial)
-        if seed is not None:
+        if seed is not None and args.streams == 1:
             np.random.seed(seed)
         res = run_single_trial(N, cfg, rng=np.random, seed=seed, device=local_rank)
         res["trial_index"] = trial
-        runs.append(res)
         status_str = "OK" if res["status"] == "success" else f"ERR ({res['error']})"
         print(f"  [rank {rank}] N={N} trial {trial+1:02d}/{cfg['trials_per_N']}  time = {res['time_sec']:.3f}s  [{status_str}]")
+        return res
+
+    jobs = jobs_for_rank(cfg, rank, world)
+    t_all = time.perf_counter()
+    if args.streams <= 1:
+        runs = [one_job(j) for j in jobs]
+    else:
+        # scenario-parallel on ONE GPU: a worker thread per HIP stream; ctypes releases the GIL inside the library
+        # and every SCP object owns its context, workspace and stream, so the solves overlap on the device
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+
+        import torch
+
+        tls = threading.local()
+
+        def on_stream(job):
+            if not hasattr(tls, "stream"):
+                torch.cuda.set_device(local_rank)
+                tls.stream = torch.cuda.Stream(device=local_rank)
+            with torch.cuda.stream(tls.stream):
+                return one_job(job)
+
+        with ThreadPoolExecutor(max_workers=args.streams) as pool:
+            runs = list(pool.map(on_stream, jobs))
+    wall = time.perf_counter() - t_all
+    if jobs:
+        print(f"  [rank {rank}] {len(jobs)} scenarios in {wall:.2f}s wall = {len(jobs)/wall:.1f} scenarios/s "
+              f"({args.streams} stream(s))")
 
     if world > 1:
         import torch.distributed as dist

@@ -39,6 +39,7 @@ class SCP:
         working_set_margin=0.5,
         feasibility_tol=1e-6,
         max_rounds=20,
+        refresh_feasibility=False,
         verbose=True,
         rank=0,
         world_size=1,
@@ -83,6 +84,7 @@ class SCP:
         self.working_set_margin = float(working_set_margin)
         self.feasibility_tol = float(feasibility_tol)
         self.max_rounds = int(max_rounds)
+        self.refresh_feasibility = bool(refresh_feasibility)
         self._qp_overrides = dict(qp_settings or {})
         self.shard = Shard(self.N, rank, world_size, group)
         if device is None:
@@ -207,6 +209,13 @@ class SCP:
                 self._print(f"Converged after {iteration+1} iterations.")
             acc = new_acc
             iteration += 1
+            if self.refresh_feasibility and not converged:
+                # opt-in (the reference leaves this as a TODO, scp.py:150): stop as soon as the new trajectories are
+                # collision free instead of waiting for the relative-step test
+                pos_now, _ = self._kinematics(acc, want_vel=False)
+                verbose, self.verbose = self.verbose, False
+                is_feasible = self._fast_check_avoidance_constraints(pos_now)
+                self.verbose = verbose
 
         positions, velocities = self._kinematics(acc)
         self.trajectories = {
@@ -396,6 +405,44 @@ class SCP:
             f"Avoidance constraint violation at timestep {k} between vehicles {i} and {j}: distance = {d:.3f}"
         )
         return False
+
+    # ------------------------------------------------------------------------------------------------
+    # post-solve validation: one device pass over all pairs + the fixed rows on the host copy
+    # ------------------------------------------------------------------------------------------------
+    def validate_solution(self):
+        """Feasibility report of the stored trajectories: minimum pair distance over all stored samples and its
+        first violation of R - 0.01 (device reduction, generalises scp.py:597-615), worst violation of every bound
+        the reference imposes (scp.py:182-257) and of the final-state equalities (state K)."""
+        if self.trajectories is None:
+            raise ValueError("Trajectories not generated yet")
+        N, K, D, h = self.N, self.K, self.D, self.h
+        a, v, p = (self.trajectories[k] for k in ("accelerations", "velocities", "positions"))
+        q0, q1 = self.shard.pair_range()
+        min_dist, first, _, _ = self._ctx.check_avoidance(N, K, D, self.R, self._ctx.tensor(p), q0, q1)
+        min_dist = self.shard.all_min(min_dist)
+        first = self.shard.all_min_int(first)
+        pf = self.final_positions.reshape(N, D)
+        vf = self.final_velocities.reshape(N, D)
+        vK = v[:, K - 1] + h * a[:, K - 1]
+        pK = p[:, K - 1] + h * v[:, K - 1] + 0.5 * h * h * a[:, K - 1]
+        over = lambda x, lo, hi: float(max(0.0, (lo - x).max(), (x - hi).max()))  # noqa: E731
+        report = {
+            "min_pair_distance": min_dist,
+            "collision_free": first >= (1 << 63) - 1,
+            "first_violation": None,
+            "acc_violation": over(a, self.acc_min, self.acc_max),
+            "jerk_violation": over(np.diff(a, axis=1) / h, self.jerk_min, self.jerk_max),
+            "vel_violation": max(over(v[:, 1:], self.vel_min, self.vel_max), over(vK, self.vel_min, self.vel_max)),
+            "pos_violation": over(p[:, 1:], np.asarray(self.pos_min, float), np.asarray(self.pos_max, float)),
+            "final_position_error": float(np.abs(pK - pf).max()),
+            "final_velocity_error": float(np.abs(vK - vf).max()),
+        }
+        if not report["collision_free"]:
+            k, q = divmod(first, self.shard.pairs)
+            i, j = pair_from_index(q, N)
+            report["first_violation"] = {"timestep": int(k), "vehicles": (i, j),
+                                         "distance": float(np.linalg.norm(p[i, k] - p[j, k]))}
+        return report
 
     # ------------------------------------------------------------------------------------------------
     # visualisation passthroughs (scp.py:644-840): host-side matplotlib over the stored numpy trajectories

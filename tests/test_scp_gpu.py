@@ -134,6 +134,27 @@ def test_initially_feasible_skips_loop():
     check_solution_properties(s, traj)
 
 
+def test_validate_solution_and_refresh_feasibility():
+    """device-side feasibility report; opt-in refresh of is_feasible inside the loop."""
+    from path_planning.scenarios.position_generator import generate_grid_swap
+
+    p0, pf, space = generate_grid_swap(36, seed=5)
+    s, traj = solve_gpu(36, 10.0, 0.2, 0.8, space, p0, pf)
+    rep = s.validate_solution()
+    prob = so.make_problem(36, 10.0, 0.2, 0.8, space, p0, pf)
+    assert abs(rep["min_pair_distance"] - so.min_pair_distance(prob, traj["positions"])) < 1e-12
+    ok, first = so.check_avoidance(prob, traj["positions"])
+    assert rep["collision_free"] == ok
+    if not ok:
+        assert (rep["first_violation"]["timestep"],) + rep["first_violation"]["vehicles"] == first[:3]
+    for key in ("acc_violation", "jerk_violation", "vel_violation", "pos_violation", "final_position_error",
+                "final_velocity_error"):
+        assert rep[key] < 3e-2, (key, rep[key])
+    s2, _ = solve_gpu(36, 10.0, 0.2, 0.8, space, p0, pf, refresh_feasibility=True)
+    assert s2.last_info["n_iterations"] <= s.last_info["n_iterations"]
+    assert s2.validate_solution()["min_pair_distance"] >= 0.8 - 0.011 or not s2.last_info["converged"]
+
+
 def test_plots_headless(tmp_path):
     p0, pf = ref_scenario(4, 1)
     s, _ = solve_gpu(4, 10.0, 0.5, 0.8, [0, 0, 20, 20], p0, pf, max_iterations=1)

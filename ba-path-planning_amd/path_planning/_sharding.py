@@ -91,6 +91,16 @@ class Shard:
                 dist.broadcast(tensor, src=src, group=self.group)
         return tensor
 
+    def broadcast_ints(self, values, src=0):
+        """Rank `src`'s integers on every rank: loop-control decisions (iteration counts, statuses) must be taken
+        from ONE rank, otherwise fp-atomics noise in the replicated QP could make ranks leave a loop at different
+        trip counts and the next collective would hang."""
+        if self.world == 1:
+            return [int(v) for v in values]
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=self._dev())
+        dist.broadcast(t, src=src, group=self.group)
+        return [int(v) for v in t.tolist()]
+
     def all_min(self, value: float) -> float:
         if self.world == 1:
             return value

@@ -257,6 +257,8 @@ class SCP:
         qp.update_settings(max_iter=int(self._qp_overrides.get("max_iter0", self._qp_overrides.get("max_iter", 4000))))
         qp.reset(None)
         info = qp.solve()
+        info["status_val"], info["iter"] = self.shard.broadcast_ints([info["status_val"], info["iter"]])
+        info["status"] = _hip.STATUS_TEXT.get(info["status_val"], str(info["status_val"]))
         self._last_qp_info = dict(info, rounds=1, added=[])
         if info["status_val"] not in (1, 2):  # Solved / Solved Inaccurate (scp.py:363-365)
             self._print("not feasible")
@@ -351,6 +353,9 @@ class SCP:
         for rnd in range(self.max_rounds):
             qp.update_settings(max_iter=max(max_iter - used, 1))
             info = qp.solve()
+            # rank 0's counters drive the loop on every rank (see Shard.broadcast_ints)
+            info["status_val"], info["iter"] = self.shard.broadcast_ints([info["status_val"], info["iter"]])
+            info["status"] = _hip.STATUS_TEXT.get(info["status_val"], str(info["status_val"]))
             used += info["iter"]
             for k in total:
                 total[k] += info[k]

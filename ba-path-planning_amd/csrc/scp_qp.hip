@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void admm_rhs_prep_kernel(int64_t nf, int64_t 
   if (t < nx) rhs[t] = sigma * x[t];
 }
 
-enum RowMode { ROW_RHS = 0, ROW_HMUL = 1, ROW_Y = 2 };
+enum RowMode { ROW_RHS = 0, ROW_HMUL = 1, ROW_Y = 2, ROW_VEC = 3 };
 
 // G[k][i] += eta g, G[k][j] -= eta g  for every working row; g depends on the mode:
 //   ROW_RHS : rho zc - yc            (right-hand side of the x-update)
@@ -84,8 +84,10 @@ __global__ __launch_bounds__(256) void row_scatter_kernel(int64_t nW, int64_t C,
 #pragma unroll
     for (int d = 0; d < D; ++d) ax += e[d] * (Q[bi + d] - Q[bj + d]);
     g = rho * ax;
-  } else {
+  } else if (MODE == ROW_Y) {
     g = yc[n];
+  } else {
+    g = zc[n];  // ROW_VEC: the caller passes an arbitrary row vector through the zc argument
   }
 #pragma unroll
   for (int d = 0; d < D; ++d) {
@@ -263,6 +265,59 @@ __global__ __launch_bounds__(256) void resid_dual_kernel(int64_t nx, const doubl
   }
 }
 
+// primal infeasibility certificate, fixed rows: dy = y - snapshot (in place), max |dy|, sum u dy+ + l dy-
+__global__ __launch_bounds__(256) void dy_fixed_kernel(int64_t nf, const double* __restrict__ yf,
+                                                        const double* __restrict__ lf, const double* __restrict__ uf,
+                                                        double* __restrict__ dyf, double* __restrict__ scal) {
+  __shared__ double ssum[4];
+  double mx = 0.0, sup = 0.0;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < nf; t += (int64_t)gridDim.x * 256) {
+    const double d = yf[t] - dyf[t];
+    dyf[t] = d;
+    mx = fmax(mx, fabs(d));
+    sup += uf[t] * fmax(d, 0.0) + lf[t] * fmin(d, 0.0);
+  }
+  mx = block_max(mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sup += __shfl_xor(sup, o);
+  if ((threadIdx.x & 63) == 0) ssum[threadIdx.x >> 6] = sup;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomic_max_nonneg(scal + SL_NDY, mx);
+    atomicAdd(scal + SL_SUPP, (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]));
+  }
+}
+
+// collision rows (u = +inf): dy = min(y - snapshot, 0)
+__global__ __launch_bounds__(256) void dy_rows_kernel(int64_t nW, const double* __restrict__ yc,
+                                                       const double* __restrict__ wl, double* __restrict__ dyc,
+                                                       double* __restrict__ scal) {
+  __shared__ double ssum[4];
+  double mx = 0.0, sup = 0.0;
+  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nW; n += (int64_t)gridDim.x * 256) {
+    const double d = fmin(yc[n] - dyc[n], 0.0);
+    dyc[n] = d;
+    mx = fmax(mx, fabs(d));
+    sup += wl[n] * d;
+  }
+  mx = block_max(mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sup += __shfl_xor(sup, o);
+  if ((threadIdx.x & 63) == 0) ssum[threadIdx.x >> 6] = sup;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomic_max_nonneg(scal + SL_NDY, mx);
+    atomicAdd(scal + SL_SUPP, (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]));
+  }
+}
+
+__global__ __launch_bounds__(256) void max_abs_kernel(int64_t n, const double* __restrict__ v, double* __restrict__ slot) {
+  double mx = 0.0;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) mx = fmax(mx, fabs(v[t]));
+  mx = block_max(mx);
+  if (threadIdx.x == 0) atomic_max_nonneg(slot, mx);
+}
+
 // Hf[a][b] = (2 + sigma) delta_ab + rho * sum_r w_r F[r][a] F[r][b];  HS = [Hf ; S0]
 __global__ __launch_bounds__(256) void build_hf_kernel(int K, int Rf, double rho, double sigma,
                                                         const double* __restrict__ F, const double* __restrict__ wrow,
@@ -396,6 +451,8 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.scal = c.take<double>(SL_COUNT);
   d.part = c.take<double>(2 * SCP_PART_CAP);
   d.hpf = c.take<double>(nx);
+  d.dyf = c.take<double>(nf);
+  d.dyc = c.take<double>((size_t)cap);
   return c.off;
 }
 
@@ -414,17 +471,17 @@ int gemm(scp_qp* qp, int R, int M, double alpha, const double* A, const double* 
 }
 
 template <int MODE>
-int row_scatter(scp_qp* qp, const double* Q) {
+int row_scatter(scp_qp* qp, const double* Q, const double* vec = nullptr) {
   const QpDev& d = qp->d;
   hipStream_t s = qp->ctx->stream;
   SCP_HIP_CHECK(qp->ctx, hipMemsetAsync(d.G, 0, (size_t)qp->K * qp->C * sizeof(double), s));
   const double rho_c = qp->rho * qp->st.rho_col_scale;
   if (qp->D == 2)
     hipLaunchKernelGGL((row_scatter_kernel<2, MODE>), grid1(qp->nW), dim3(256), 0, s, qp->nW, qp->C, rho_c, d.w_k,
-                       d.w_i, d.w_j, d.w_eta, d.zc, d.yc, Q, d.G);
+                       d.w_i, d.w_j, d.w_eta, vec ? vec : d.zc, d.yc, Q, d.G);
   else
     hipLaunchKernelGGL((row_scatter_kernel<3, MODE>), grid1(qp->nW), dim3(256), 0, s, qp->nW, qp->C, rho_c, d.w_k,
-                       d.w_i, d.w_j, d.w_eta, d.zc, d.yc, Q, d.G);
+                       d.w_i, d.w_j, d.w_eta, vec ? vec : d.zc, d.yc, Q, d.G);
   QP_LAUNCHED(qp);
   return SCP_OK;
 }
@@ -519,14 +576,24 @@ int admm_iteration(scp_qp* qp, int* cg_count) {
   return SCP_OK;
 }
 
-// residuals -> qp->h_scal[SL_RP..SL_NATY] (synchronises the stream)
-int residuals(scp_qp* qp) {
+// residuals -> qp->h_scal[SL_RP..SL_NATY]; with_dy: also delta-y = y - snapshot, its max norm and support value
+// (SL_NDY, SL_SUPP).  Synchronises the stream.
+int residuals(scp_qp* qp, bool with_dy) {
   const QpDev& d = qp->d;
   scp_ctx* ctx = qp->ctx;
   hipStream_t s = ctx->stream;
   const int K = qp->K, Rf = qp->Rf;
   const int64_t C = qp->C, nf = (int64_t)Rf * C, nx = (int64_t)K * C;
-  SCP_HIP_CHECK(ctx, hipMemsetAsync(d.scal + SL_RP, 0, 6 * sizeof(double), s));
+  SCP_HIP_CHECK(ctx, hipMemsetAsync(d.scal + SL_RP, 0, 9 * sizeof(double), s));
+  if (with_dy) {
+    hipLaunchKernelGGL(dy_fixed_kernel, dim3(256), dim3(256), 0, s, nf, d.yf, d.lf, d.uf, d.dyf, d.scal);
+    QP_LAUNCHED(qp);
+    if (qp->nW > 0) {
+      const int blocks = (int)((qp->nW + 255) / 256) < 256 ? (int)((qp->nW + 255) / 256) : 256;
+      hipLaunchKernelGGL(dy_rows_kernel, dim3(blocks), dim3(256), 0, s, qp->nW, d.yc, d.w_l, d.dyc, d.scal);
+      QP_LAUNCHED(qp);
+    }
+  }
   QP_CHECK(gemm(qp, Rf, K, 1.0, d.F, d.x, 0.0, d.tf));
   hipLaunchKernelGGL(resid_fixed_kernel, dim3(256), dim3(256), 0, s, nf, d.tf, d.zf, d.scal);
   QP_LAUNCHED(qp);
@@ -552,6 +619,26 @@ int residuals(scp_qp* qp) {
   return SCP_OK;
 }
 
+// second half of the certificate: || A^T dy ||_inf -> h_scal[SL_NATDY] (synchronises)
+int certificate_atdy(scp_qp* qp) {
+  const QpDev& d = qp->d;
+  scp_ctx* ctx = qp->ctx;
+  hipStream_t s = ctx->stream;
+  const int K = qp->K, Rf = qp->Rf;
+  const int64_t nx = (int64_t)K * qp->C;
+  SCP_HIP_CHECK(ctx, hipMemsetAsync(d.scal + SL_NATDY, 0, sizeof(double), s));
+  QP_CHECK(gemm(qp, K, Rf, 1.0, d.Ft, d.dyf, 0.0, d.rhs));
+  if (qp->nW > 0) {
+    QP_CHECK(row_scatter<ROW_VEC>(qp, nullptr, d.dyc));
+    QP_CHECK(gemm(qp, K, K, 1.0, d.S0t, d.G, 1.0, d.rhs));
+  }
+  hipLaunchKernelGGL(max_abs_kernel, dim3(128), dim3(256), 0, s, nx, d.rhs, d.scal + SL_NATDY);
+  QP_LAUNCHED(qp);
+  SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->h_scal + SL_NATDY, d.scal + SL_NATDY, sizeof(double), hipMemcpyDeviceToHost, s));
+  SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  return SCP_OK;
+}
+
 }  // namespace
 
 // ----------------------------------------------------------------------------------------------------
@@ -573,6 +660,7 @@ extern "C" void scp_qp_default_settings(scp_qp_settings* s) {
   s->cg_iters = 1;
   s->use_mfma = 1;
   s->rho_col_scale = 10.0;
+  s->eps_prim_inf = 1e-4;
 }
 
 extern "C" size_t scp_qp_workspace_bytes(int N, int K, int D, int64_t row_capacity) {
@@ -731,11 +819,20 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
   double rp = INFINITY, rd = INFINITY;
   while (it < st.max_iter) {
     ++it;
+    const bool will_check = it % st.check_termination == 0 || it >= st.max_iter;
+    const bool with_dy = will_check && st.eps_prim_inf > 0.0;
+    if (with_dy) {  // snapshot of the duals: delta-y of this iteration feeds the infeasibility certificate
+      SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->d.dyf, qp->d.yf, (size_t)qp->Rf * qp->C * sizeof(double),
+                                        hipMemcpyDeviceToDevice, ctx->stream));
+      if (qp->nW > 0)
+        SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->d.dyc, qp->d.yc, (size_t)qp->nW * sizeof(double),
+                                          hipMemcpyDeviceToDevice, ctx->stream));
+    }
     if (fused && st.cg_iters == 1 && qp->nW > 0) QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total));
     else if (fused) QP_CHECK(scp_qp_fused_iteration(qp, &cg_total));
     else QP_CHECK(admm_iteration(qp, &cg_total));
-    if (it % st.check_termination == 0 || it >= st.max_iter) {
-      QP_CHECK(residuals(qp));
+    if (will_check) {
+      QP_CHECK(residuals(qp, with_dy));
       qp->cg1_ready = false;  // residuals() used G and the Q slabs as scratch; rho may change below
       const double* hs = qp->h_scal;
       rp = hs[SL_RP];
@@ -745,6 +842,16 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
       if (rp <= st.eps_abs + st.eps_rel * np && rd <= st.eps_abs + st.eps_rel * nd) {
         info->status_val = 1;
         break;
+      }
+      if (with_dy) {  // OSQP's is_primal_infeasible on the unscaled problem
+        const double ndy = hs[SL_NDY], supp = hs[SL_SUPP];
+        if (ndy > st.eps_prim_inf && supp < -st.eps_prim_inf * ndy) {
+          QP_CHECK(certificate_atdy(qp));
+          if (qp->h_scal[SL_NATDY] < st.eps_prim_inf * ndy) {
+            info->status_val = -3;
+            break;
+          }
+        }
       }
       if (st.adaptive_rho && st.adaptive_rho_interval > 0 && it % st.adaptive_rho_interval == 0) {
         const double prim = rp / fmax(np, 1e-10);

@@ -7,6 +7,7 @@ constexpr int NPART = 128;  // partial sums of a dot product (fixed -> determini
 enum Slot {  // device scalar slots (doubles)
   SL_RZ0 = 0, SL_RZ1 = 1,
   SL_RP = 8, SL_NAX = 9, SL_NZ = 10, SL_RD = 11, SL_NPX = 12, SL_NATY = 13,
+  SL_NDY = 14, SL_SUPP = 15, SL_NATDY = 16,
   SL_COUNT = 32
 };
 
@@ -26,6 +27,8 @@ struct QpDev {
   double* scal;   // SL_COUNT
   double* part;   // 2 * SCP_PART_CAP
   double* hpf;    // [K][C]: H_f p of the fused PCG
+  double* dyf;    // [Rf][C]: snapshot of y_f, then delta-y (primal infeasibility certificate)
+  double* dyc;    // [cap]  : same for the working rows
 };
 
 struct scp_qp {

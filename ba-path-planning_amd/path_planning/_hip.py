@@ -35,7 +35,7 @@ class QpSettings(C.Structure):
         ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("max_iter", C.c_int32),
         ("check_termination", C.c_int32), ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32),
         ("adaptive_rho_tolerance", C.c_double), ("cg_iters", C.c_int32), ("use_mfma", C.c_int32),
-        ("rho_col_scale", C.c_double),
+        ("rho_col_scale", C.c_double), ("eps_prim_inf", C.c_double),
     ]
 
 

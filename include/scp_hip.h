@@ -71,11 +71,13 @@ typedef struct scp_qp_settings {
   double rho_col_scale;          /* 10: rho of the collision rows = rho * rho_col_scale (like OSQP's per-row rho,
                                     which the reference gets x 1e3 on equality rows only).  Measured at 1024 x 50:
                                     the same SCP iterates with 3.5 x fewer ADMM iterations than scale 1 */
+  double eps_prim_inf;           /* 1e-4: OSQP's primal infeasibility tolerance; the certificate (delta-y test) is
+                                    evaluated at every termination check; <= 0 disables it */
 } scp_qp_settings;
 
 /* [host] result of scp_qp_solve */
 typedef struct scp_qp_info {
-  int32_t status_val;   /* OSQP codes: 1 solved, -2 maximum iterations reached */
+  int32_t status_val;   /* OSQP codes: 1 solved, -2 maximum iterations reached, -3 primal infeasible */
   int32_t iter;         /* ADMM iterations of this call */
   int32_t rho_updates;
   int32_t cg_iters_total;

@@ -202,6 +202,7 @@ class Settings:
     feas_tol: float = 1e-6    # a non-working row enters W when (A x)_r < l_r - feas_tol
     max_rounds: int = 20      # constraint-generation rounds
     rho_col_scale: float = 10.0  # rho of the collision rows = rho * rho_col_scale
+    eps_prim_inf: float = 1e-4   # OSQP's primal infeasibility tolerance (certificate test at every check)
 
 
 class FixedOps:
@@ -350,6 +351,9 @@ def admm_structured(prob: so.Problem, eta=None, l_col=None, dist=None, x0=None, 
             else:
                 xt = np.einsum("km,imd->ikd", M, rhs)
             # z~ = A x~ ; relaxation ; projection ; dual update
+            will_check = (it % st.check_termination == 0) or total_it >= st.max_iter
+            if will_check:
+                y_prev = (yj, ya, yv, yp, yc)
             tj, ta, tv, tp = ops.apply(xt)
             al = st.alpha
             x_new = al * xt + (1 - al) * x
@@ -390,6 +394,26 @@ def admm_structured(prob: so.Problem, eta=None, l_col=None, dist=None, x0=None, 
                 if rp_ <= st.eps_abs + st.eps_rel * max(nAx, nz) and rd_ <= st.eps_abs + st.eps_rel * max(nPx, nATy):
                     status = OSQP_SOLVED
                     break
+                # primal infeasibility certificate (OSQP is_primal_infeasible): dy = y - y_prev projected onto the
+                # polar of the recession cone (collision rows have u = +inf -> dy := min(dy, 0)); all fixed rows
+                # have finite bounds
+                dj, da, dv, dp = yj - y_prev[0], ya - y_prev[1], yv - y_prev[2], yp - y_prev[3]
+                dc = np.minimum(yc - y_prev[4], 0.0) if W.size else np.zeros(0)
+                ndy = max(np.abs(dj).max(), np.abs(da).max(), np.abs(dv).max(), np.abs(dp).max(),
+                          np.abs(dc).max() if W.size else 0.0)
+                if ndy > st.eps_prim_inf:
+                    supp = 0.0
+                    for dd, (lo, hi) in ((dj, (lj, uj)), (da, (la, ua)), (dv, (lv, uv)), (dp, (lp, up))):
+                        supp += float(np.sum(hi * np.maximum(dd, 0.0) + lo * np.minimum(dd, 0.0)))
+                    if W.size:
+                        supp += float(np.sum(wl * dc))
+                    if supp < -st.eps_prim_inf * ndy:
+                        ATdy = ops.apply_T(dj, da, dv, dp)
+                        if W.size:
+                            ATdy = ATdy + col_apply_T(dc, wk, wi, wj_, we)
+                        if np.abs(ATdy).max() < st.eps_prim_inf * ndy:
+                            status = OSQP_PRIMAL_INFEASIBLE
+                            break
                 if st.adaptive_rho and it % st.adaptive_rho_interval == 0:
                     prim = rp_ / max(nAx, nz, 1e-10)
                     dual = rd_ / max(nPx, nATy, 1e-10)
@@ -399,7 +423,7 @@ def admm_structured(prob: so.Problem, eta=None, l_col=None, dist=None, x0=None, 
                         rvv, rpp, M, Hf = build(rho)
                         info["rho_updates"] += 1
         # constraint generation: check every collision row outside W at the ADMM solution
-        if not have_col:
+        if not have_col or status == OSQP_PRIMAL_INFEASIBLE:
             break
         ax_all = so.collision_apply(prob, eta, x.ravel())
         viol = ax_all < l_col - st.feas_tol

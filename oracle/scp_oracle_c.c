@@ -33,6 +33,7 @@ typedef struct {
   double margin, feas_tol;
   int max_rounds;
   double rho_col_scale; /* rho of the collision rows = rho * rho_col_scale */
+  double eps_prim_inf;  /* OSQP's primal infeasibility tolerance */
 } oc_settings;
 
 typedef struct {
@@ -282,6 +283,7 @@ int oc_admm(const oc_problem* P, const double* eta, const double* l_col, const d
   double *tj = NEWV(nx), *ta = NEWV(nx), *tv = NEWV(nx), *tp = NEWV(nx);
   double *lv = NEWV(nx), *uv = NEWV(nx), *lp = NEWV(nx), *up = NEWV(nx);
   double *Hf = NEWV((size_t)K * K), *Minv = NEWV((size_t)K * K), *Qs = NEWV(nx), *Gs = NEWV(nx);
+  double *sj = NEWV(nx), *sa = NEWV(nx), *sv = NEWV(nx), *sp = NEWV(nx), *sc = NULL; /* y snapshots -> dy */
   /* bounds (scp.py:206-257), column layout */
   for (int i = 0; i < N; ++i)
     for (int d = 0; d < D; ++d) {
@@ -407,6 +409,12 @@ int oc_admm(const oc_problem* P, const double* eta, const double* l_col, const d
       }
       /* z~ = A x~, relaxation, projection, duals */
       const double al = st->alpha;
+      const int will_check = (it % st->check_termination == 0) || total_it >= st->max_iter;
+      if (will_check) {
+        memcpy(sj, yj, sizeof(double) * nx); memcpy(sa, ya, sizeof(double) * nx);
+        memcpy(sv, yv, sizeof(double) * nx); memcpy(sp, yp, sizeof(double) * nx);
+        if (nW > 0) { sc = realloc(sc, sizeof(double) * nW); memcpy(sc, yc, sizeof(double) * nW); }
+      }
       for (int c = 0; c < C; ++c) {
         const size_t o = (size_t)c * K;
         f_apply(K, h, xt + o, tj + o, ta + o, tv + o, tp + o);
@@ -474,6 +482,43 @@ int oc_admm(const oc_problem* P, const double* eta, const double* l_col, const d
           status = 1;
           break;
         }
+        { /* primal infeasibility certificate (OSQP is_primal_infeasible), as in qp_oracle.admm_structured */
+          double ndy = 0.0, supp = 0.0;
+          for (int c = 0; c < C; ++c) {
+            const size_t o = (size_t)c * K;
+            for (int k = 0; k < K; ++k) {
+              double d;
+              if (k < K - 1) {
+                d = sj[o + k] = yj[o + k] - sj[o + k]; ndy = dmax(ndy, fabs(d));
+                supp += P->jerk_max * dmax(d, 0.0) + P->jerk_min * dmin(d, 0.0);
+              } else sj[o + k] = 0.0;
+              d = sa[o + k] = ya[o + k] - sa[o + k]; ndy = dmax(ndy, fabs(d));
+              supp += P->acc_max * dmax(d, 0.0) + P->acc_min * dmin(d, 0.0);
+              d = sv[o + k] = yv[o + k] - sv[o + k]; ndy = dmax(ndy, fabs(d));
+              supp += uv[o + k] * dmax(d, 0.0) + lv[o + k] * dmin(d, 0.0);
+              d = sp[o + k] = yp[o + k] - sp[o + k]; ndy = dmax(ndy, fabs(d));
+              supp += up[o + k] * dmax(d, 0.0) + lp[o + k] * dmin(d, 0.0);
+            }
+          }
+          for (int64_t n = 0; n < nW; ++n) {
+            const double d = sc[n] = dmin(yc[n] - sc[n], 0.0);
+            ndy = dmax(ndy, fabs(d));
+            supp += wl[n] * d;
+          }
+          if (ndy > st->eps_prim_inf && supp < -st->eps_prim_inf * ndy) {
+            double nat = 0.0;
+            for (int c = 0; c < C; ++c) {
+              const size_t o = (size_t)c * K;
+              ft_apply(K, h, sj + o, sa + o, sv + o, sp + o, rhs + o);
+            }
+            if (nW > 0) rows_apply_T_add(&R, sc, rhs);
+            for (size_t e = 0; e < nx; ++e) nat = dmax(nat, fabs(rhs[e]));
+            if (nat < st->eps_prim_inf * ndy) {
+              status = -3;
+              break;
+            }
+          }
+        }
         if (st->adaptive_rho && it % st->adaptive_rho_interval == 0) {
           const double prim = rp / dmax(dmax(nAx, nz), 1e-10), dual = rd / dmax(dmax(nPx, nATy), 1e-10);
           double nr = rho * sqrt(prim / dmax(dual, 1e-10));
@@ -487,7 +532,7 @@ int oc_admm(const oc_problem* P, const double* eta, const double* l_col, const d
         }
       }
     }
-    if (!eta) break;
+    if (!eta || status == -3) break;
     /* constraint generation: every row outside W checked at the ADMM solution */
     if (!ax_all) ax_all = malloc(sizeof(double) * (size_t)m_col);
     for (int c = 0; c < C; ++c) s0_apply(K, h, x + (size_t)c * K, Qs + (size_t)c * K);
@@ -524,6 +569,6 @@ int oc_admm(const oc_problem* P, const double* eta, const double* l_col, const d
   free(x); free(xt); free(rhs); free(r); free(p); free(zz); free(Hp); free(zj); free(za); free(zv); free(zp);
   free(yj); free(ya); free(yv); free(yp); free(tj); free(ta); free(tv); free(tp); free(lv); free(uv); free(lp);
   free(up); free(Hf); free(Minv); free(Qs); free(Gs); free(wrow); free(inW); free(wk); free(wi); free(wj);
-  free(weta); free(wl); free(zc); free(yc); free(tc); free(gc); free(ax_all);
+  free(weta); free(wl); free(zc); free(yc); free(tc); free(gc); free(ax_all); free(sj); free(sa); free(sv); free(sp); free(sc);
   return 0;
 }

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.scp_abi_version() == 1
     # struct layouts agree with the header
-    assert ctypes.sizeof(_hip.QpSettings) == 88 and ctypes.sizeof(_hip.QpInfo) == 56  # == sizeof in C (checked with g++)
+    assert ctypes.sizeof(_hip.QpSettings) == 96 and ctypes.sizeof(_hip.QpInfo) == 56  # == sizeof in C (checked with g++)
     s = _hip.default_settings()
     assert (s.rho, s.sigma, s.alpha, s.eps_abs, s.eps_rel, s.max_iter, s.check_termination) == (
         0.1, 1e-6, 1.6, 1e-3, 1e-3, 4000, 25)  # OSQP defaults

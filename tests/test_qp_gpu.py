@@ -135,6 +135,47 @@ def test_collision_qp_matches_oracle(ctx, n, seed, T, h, margin):
     assert np.abs(x.ravel() - r["x"]).max() < 5e-4  # eps = 1e-6 ADMM point vs the exact minimiser
 
 
+def test_primal_infeasibility_certificate(ctx):
+    """OSQP's delta-y certificate: (i) an unreachable goal makes QP#0 infeasible; (ii) the FIRST linearised QP of the
+    reference's own __main__ demo (3 vehicles crossing in T = 3 s, scp.py:844-862) is primal infeasible -- the
+    explicit-matrix OSQP restatement says so too.  GPU, numpy oracle and C oracle stop at the same iteration."""
+    import torch
+
+    from oracle import c_oracle as co
+
+    far = so.make_problem(2, 1.0, 0.2, 0.5, [0, 0, 20, 20], np.array([[1.0, 1.0], [3.0, 3.0]]),
+                          np.array([[19.0, 19.0], [15.0, 3.0]]))
+    qp = make_qp(ctx, far, cg_iters=1)
+    qp.reset(None)
+    info = qp.solve()
+    _, _, io = qo.admm_structured(far, st=qo.Settings(max_iter=4000))
+    assert info["status_val"] == io["status_val"] == -3 and info["status"] == "primal infeasible"
+    assert info["iter"] == io["iter"] == co.admm(far, st=qo.Settings(max_iter=4000))[1]["iter"]
+    qp.close()
+
+    p0 = np.array([[-2.0, -2.0], [0.0, -2.0], [2.0, -2.0]])
+    pf = np.array([[2.0, 2.0], [0.0, 2.0], [-2.0, 2.0]])
+    prob = so.make_problem(3, 3.0, 0.2, 0.5, [-5, -5, 500, 200], p0, pf)
+    x0, _, i0 = qo.admm_structured(prob, st=qo.Settings(max_iter=4000))
+    assert i0["status_val"] == 1
+    pos, _ = so.kinematics(prob, x0)
+    eta, l_col, dist = so.linearize_pairs(prob, pos)
+    st = qo.Settings(max_iter=10000)
+    _, _, io = qo.admm_structured(prob, eta, l_col, dist, x0=x0, st=st)
+    W = np.nonzero(dist - prob.R < st.margin)[0]
+    qp = make_qp(ctx, prob, cg_iters=1, max_iter=10000)
+    qp.reset(ctx.tensor(x0))
+    qp.add_rows(torch.as_tensor(W, dtype=torch.int64, device=ctx.tdev), ctx.tensor(eta[W]), ctx.tensor(l_col[W]))
+    info = qp.solve()
+    assert info["status_val"] == io["status_val"] == -3 and info["iter"] == io["iter"]
+    C, lf, uf = so.stack_fixed(prob)
+    A = sp.vstack([C, so.collision_matrix_explicit(prob, eta)], format="csc")
+    r = qo.osqp_explicit(2 * sp.eye(prob.n, format="csc"), np.zeros(prob.n), A, np.hstack([lf, l_col]),
+                         np.hstack([uf, np.full(l_col.size, np.inf)]), x0=x0.ravel(), max_iter=10000)
+    assert r["status_val"] == -3
+    qp.close()
+
+
 def test_qp_3d_z0_metamorphic(ctx):
     """D=3 with z == 0 everywhere reproduces the D=2 solution."""
     prob2 = ref_problem(6, 3, 10.0, 0.5)

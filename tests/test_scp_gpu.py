@@ -116,13 +116,21 @@ def test_api_surface_and_errors(capsys):
         s.visualize_time_snapshots()
     with pytest.raises(AssertionError):
         s.set_initial_states(np.zeros((4, 2)))
-    # QP#0 infeasible (goal unreachable in T) -> RuntimeError("OSQP failed: ...") like scp.py:363-365
-    s = SCP(n_vehicles=2, time_horizon=1.0, time_step=0.2, min_distance=0.5, verbose=False,
-            qp_settings={"max_iter0": 200})
+    # QP#0 infeasible (goal unreachable in T) -> RuntimeError("OSQP failed: primal infeasible") like scp.py:363-365
+    s = SCP(n_vehicles=2, time_horizon=1.0, time_step=0.2, min_distance=0.5, verbose=False)
     s.set_initial_states(np.array([[1.0, 1.0], [3.0, 3.0]]))
     s.set_final_states(np.array([[19.0, 19.0], [15.0, 3.0]]))
-    with pytest.raises(RuntimeError, match="OSQP failed"):
+    with pytest.raises(RuntimeError, match="OSQP failed: primal infeasible"):
         s.generate_trajectories()
+    # a later QP that is infeasible only warns and the loop goes on (scp.py:446-447): the reference's __main__ demo
+    s = SCP(n_vehicles=3, time_horizon=3.0, time_step=0.2, min_distance=0.5, space_dims=[-5, -5, 500, 200])
+    s.set_initial_states(np.array([[-2.0, -2.0], [0.0, -2.0], [2.0, -2.0]]))
+    s.set_final_states(np.array([[2.0, 2.0], [0.0, 2.0], [-2.0, 2.0]]))
+    capsys.readouterr()
+    traj = s.generate_trajectories(max_iterations=2)
+    out = capsys.readouterr().out
+    assert "Warning: OSQP status primal infeasible" in out and "SCP Iteration 1" in out
+    assert np.isfinite(traj["positions"]).all()
 
 
 def test_initially_feasible_skips_loop():

@@ -425,6 +425,7 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.Minv = c.take<double>((size_t)K * K);
   d.aug = c.take<double>((size_t)2 * K * K);
   d.wrow = c.take<double>((size_t)Rf);
+  d.MS = c.take<double>((size_t)2 * K * K);
   const size_t nf = (size_t)Rf * C, nx = (size_t)K * C;
   d.lf = c.take<double>(nf);
   d.uf = c.take<double>(nf);
@@ -514,6 +515,9 @@ int build_kkt(scp_qp* qp) {
   QP_LAUNCHED(qp);
   hipLaunchKernelGGL(spd_inverse_kernel, dim3(1), dim3(1024), (size_t)3 * K * sizeof(double), s, K, d.aug, d.Minv);
   QP_LAUNCHED(qp);
+  // MS = [Minv ; S0 Minv]: p and S0 p from one product in the single-step pipeline
+  SCP_HIP_CHECK(qp->ctx, hipMemcpyAsync(d.MS, d.Minv, (size_t)K * K * sizeof(double), hipMemcpyDeviceToDevice, s));
+  QP_CHECK(scp_launch_gemm(qp->ctx, 1, K, K, K, 1.0, d.S0, d.Minv, 0.0, d.MS + (size_t)K * K));
   return SCP_OK;
 }
 

@@ -24,7 +24,9 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // while the MFMAs of the current chunk issue (one L2 latency per product instead of one per chunk).
 // Operand maps of v_mfma_f64_16x16x4_f64 as in scp_gemm.hip.  Caller synchronises before reading O.
 template <bool ACC>
-__device__ inline void wg_mm(const double* __restrict__ A, int R, int M, const double* V, double* O, int w0, int nw) {
+__device__ inline void wg_mm_range(const double* __restrict__ A, int R, int M, int kb, int ke, const double* V, double* O,
+                                   int w0, int nw) {
+  // O[R][16] (+)= A[R][kb:ke] . V[kb:ke][16]   (A has leading dimension M, V is indexed by the absolute k)
   const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) - w0;
   if (wave < 0 || wave >= nw) return;
   const int li = lane & 15, lk = lane >> 4;
@@ -45,23 +47,23 @@ __device__ inline void wg_mm(const double* __restrict__ A, int R, int M, const d
     double a[16], an[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const int kk = 4 * s + lk;
-      a[s] = (rok && kk < M) ? Ap[kk] : 0.0;
+      const int kk = kb + 4 * s + lk;
+      a[s] = (rok && kk < ke) ? Ap[kk] : 0.0;
     }
-    for (int kc = 0; kc < M; kc += 64) {
-      const bool more = kc + 64 < M;  // wave-uniform
+    for (int kc = kb; kc < ke; kc += 64) {
+      const bool more = kc + 64 < ke;  // wave-uniform
       if (more) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
           const int kk = kc + 64 + 4 * s + lk;
-          an[s] = (rok && kk < M) ? Ap[kk] : 0.0;
+          an[s] = (rok && kk < ke) ? Ap[kk] : 0.0;
         }
       }
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        if (kc + 4 * s < M) {  // wave-uniform
+        if (kc + 4 * s < ke) {  // wave-uniform
           const int kk = kc + 4 * s + lk;
-          const double b = kk < M ? V[kk * CB + li] : 0.0;
+          const double b = kk < ke ? V[kk * CB + li] : 0.0;
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b, acc, 0, 0, 0);
         }
       }
@@ -76,6 +78,11 @@ __device__ inline void wg_mm(const double* __restrict__ A, int R, int M, const d
       if (row < R) O[row * CB + li] = acc[r];
     }
   }
+}
+
+template <bool ACC>
+__device__ inline void wg_mm(const double* __restrict__ A, int R, int M, const double* V, double* O, int w0, int nw) {
+  wg_mm_range<ACC>(A, R, M, 0, M, V, O, w0, nw);
 }
 
 // tile <-> global ([rows][C] slab, columns c0 .. c0+15); out-of-range columns read as 0 and are not written
@@ -432,8 +439,8 @@ __global__ __launch_bounds__(256) void fused_row_update_kernel(int64_t nW, int64
 //
 // so neither H p nor a second scatter is needed, and because x+ = alpha x~ + (1-alpha) x the slab Qx = S0 x follows
 // the recurrence Qx+ = alpha Qt + (1-alpha) Qx (refreshed exactly at every termination check).  Per step:
-//   colA     : W, rhsF = sigma x + F^T W, Hx = H_f x, r = rhsF - Hx + S0^T G, p = Minv r, [HpF; Qp] = [H_f; S0] p,
-//              partials r.p and p.HpF; G = 0
+//   colA     : W; r = sigma x + F^T W - H_f x + S0^T G (four products side by side); [p; Qp] = [Minv; S0 Minv] r;
+//              partials r.p (H_f p = r, so p.H_f p = r.p); G = 0
 //   rows_sq  : partials rho (eta.dQp)^2
 //   post1    : a; x~ = x + a p; z~ = F x~, Qt = S0 x~; fixed rows' z, y; x+; Qx+
 //   rows_ui  : collision rows' z, y from Qt; then G += eta (rho zc - yc - rho eta.dQx+)   (next step's scatter)
@@ -442,18 +449,22 @@ constexpr int SQ_BLOCKS = 128;
 
 __global__ __launch_bounds__(FT) void cg1_colA_kernel(int K, int Rf, int64_t C, double rho, double sigma,
                                                        const double* __restrict__ Ft, const double* __restrict__ HS,
-                                                       const double* __restrict__ S0t, const double* __restrict__ Minv,
+                                                       const double* __restrict__ S0t, const double* __restrict__ MS,
                                                        const double* __restrict__ wrow, const double* __restrict__ x,
                                                        const double* __restrict__ zf, const double* __restrict__ yf,
                                                        double* __restrict__ G, double* __restrict__ p,
-                                                       double* __restrict__ Qp, double* __restrict__ part_rz,
-                                                       double* __restrict__ part_php) {
+                                                       double* __restrict__ Qp, double* __restrict__ part_rz) {
+  // Two MFMA phases.  A: four independent products side by side on four wave groups -- F^T W split in two halves
+  // of its inner dimension, H_f x, S0^T G.  B: [p ; Qp] = [Minv ; S0 Minv] r  (H_f p = r needs no product, so
+  // p.H p = r.p + rho sum_rows (eta.dQp)^2 and the only inner product left is r.p).
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* X = lds;                  // [K][16]    later: p tile
-  double* W = X + K * CB;           // [Rf][16]   later: [HpF ; Qp] (2K <= Rf rows)
-  double* T1 = W + Rf * CB;         // [K][16]    rhsF, then r
-  double* T2 = T1 + K * CB;         // [K][16]    H_f x
-  double* Gt = T2 + K * CB;         // [K][16]
+  double* X = lds;                  // [K][16]
+  double* W = X + K * CB;           // [Rf][16]   later: [p ; Qp] (2K <= Rf rows)
+  double* Gt = W + Rf * CB;         // [K][16]
+  double* T1 = Gt + K * CB;         // [K][16]    F^T W (first half), then r
+  double* T1b = T1 + K * CB;        // [K][16]    F^T W (second half)
+  double* T2 = T1b + K * CB;        // [K][16]    H_f x
+  double* T3 = T2 + K * CB;         // [K][16]    S0^T G
   const int64_t c0 = (int64_t)blockIdx.x * CB;
   tile_load(X, x, K, C, c0);
   tile_load(Gt, G, K, C, c0);
@@ -464,31 +475,25 @@ __global__ __launch_bounds__(FT) void cg1_colA_kernel(int K, int Rf, int64_t C, 
   }
   __syncthreads();
   tile_zero_global(G, K, C, c0);
-  wg_mm<false>(Ft, K, Rf, W, T1, 0, 8);            // F^T W
+  const int half = ((Rf / 2) + 3) & ~3;
+  wg_mm_range<false>(Ft, K, Rf, 0, half, W, T1, 0, 4);
+  wg_mm_range<false>(Ft, K, Rf, half, Rf, W, T1b, 4, 4);
   wg_mm<false>(HS, K, K, X, T2, 8, 4);             // H_f x   (first K rows of [H_f; S0])
+  wg_mm<false>(S0t, K, K, Gt, T3, 12, NWV - 12);
   __syncthreads();
-  for (int e = threadIdx.x; e < K * CB; e += FT) T1[e] = (T1[e] + sigma * X[e]) - T2[e];
+  for (int e = threadIdx.x; e < K * CB; e += FT) T1[e] = ((T1[e] + T1b[e]) + sigma * X[e]) - T2[e] + T3[e];  // r
   __syncthreads();
-  wg_mm<true>(S0t, K, K, Gt, T1, 0, NWV);          // r = rhsF - Hx + S0^T G
+  wg_mm<false>(MS, 2 * K, K, T1, W, 0, NWV);       // [p ; Qp]
   __syncthreads();
-  wg_mm<false>(Minv, K, K, T1, X, 0, NWV);         // p = Minv r  (X tile reused)
-  __syncthreads();
-  wg_mm<false>(HS, 2 * K, K, X, W, 0, NWV);        // [HpF ; Qp]  (W tile reused)
   double rz = 0.0;
-  for (int e = threadIdx.x; e < K * CB; e += FT) rz += T1[e] * X[e];
+  for (int e = threadIdx.x; e < K * CB; e += FT) rz += T1[e] * W[e];
   rz = wg_sum(rz);
-  double php = 0.0;
-  for (int e = threadIdx.x; e < K * CB; e += FT) php += X[e] * W[e];
-  php = wg_sum(php);
-  if (threadIdx.x == 0) {
-    part_rz[blockIdx.x] = rz;
-    part_php[blockIdx.x] = php;
-  }
+  if (threadIdx.x == 0) part_rz[blockIdx.x] = rz;
   for (int e = threadIdx.x; e < K * CB; e += FT) {
     const int rr = e >> 4, c = e & 15;
     if (c0 + c < C) {
       const int64_t g = (int64_t)rr * C + c0 + c;
-      p[g] = X[e];
+      p[g] = W[e];
       Qp[g] = W[K * CB + e];
     }
   }
@@ -518,7 +523,6 @@ __global__ __launch_bounds__(256) void cg1_rows_sq_kernel(int64_t nW, int64_t C,
 
 __global__ __launch_bounds__(FT) void cg1_post_kernel(int K, int Rf, int64_t C, double rho, double alpha, int nblk,
                                                        const double* __restrict__ part_rz,
-                                                       const double* __restrict__ part_php,
                                                        const double* __restrict__ part_sq,
                                                        const double* __restrict__ pdir, const double* __restrict__ F,
                                                        const double* __restrict__ S0, const double* __restrict__ wrow,
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(FT) void cg1_post_kernel(int K, int Rf, int64_t C, 
   double* Q1 = T + Rf * CB;         // [K][16]   S0 x~
   const int64_t c0 = (int64_t)blockIdx.x * CB;
   const double rz = sum_parts(part_rz, nblk);
-  const double pHp = sum_parts(part_php, nblk) + sum_parts(part_sq, SQ_BLOCKS);
+  const double pHp = rz + sum_parts(part_sq, SQ_BLOCKS);  // p.H_f p = p.r because p = H_f^{-1} r
   const double a = (pHp > 0.0 && rz != 0.0) ? rz / pHp : 0.0;
   for (int e = threadIdx.x; e < K * CB; e += FT) {
     const int r = e >> 4, c = e & 15;
@@ -727,15 +731,14 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count) {
   double* Qt = d.HQ;        // S0 x~
   double* Qp = d.hpf;       // S0 p
   double* part_rz = d.part;
-  double* part_php = d.part + SCP_PART_CAP;
   double* part_sq = d.part + SCP_PART_CAP / 2;
   const double rho_c = qp->rho * qp->st.rho_col_scale;
   if (!qp->cg1_ready) {
     int rc = scp_qp_cg1_prepare(qp);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(cg1_colA_kernel, cgrid, cblock, (size_t)(4 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.sigma, d.Ft,
-                     d.HS, d.S0t, d.Minv, d.wrow, d.x, d.zf, d.yf, d.G, d.p, Qp, part_rz, part_php);
+  hipLaunchKernelGGL(cg1_colA_kernel, cgrid, cblock, (size_t)(6 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.sigma, d.Ft,
+                     d.HS, d.S0t, d.MS, d.wrow, d.x, d.zf, d.yf, d.G, d.p, Qp, part_rz);
   FUSED_LAUNCHED(qp);
   if (qp->D == 2)
     hipLaunchKernelGGL(cg1_rows_sq_kernel<2>, dim3(SQ_BLOCKS), rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
@@ -745,7 +748,7 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count) {
                        d.w_eta, Qp, part_sq);
   FUSED_LAUNCHED(qp);
   hipLaunchKernelGGL(cg1_post_kernel, cgrid, cblock, (size_t)(2 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.alpha, nblk,
-                     part_rz, part_php, part_sq, d.p, d.F, d.S0, d.wrow, d.lf, d.uf, d.zf, d.yf, d.x, Qt, Qx);
+                     part_rz, part_sq, d.p, d.F, d.S0, d.wrow, d.lf, d.uf, d.zf, d.yf, d.x, Qt, Qx);
   FUSED_LAUNCHED(qp);
   if (qp->D == 2)
     hipLaunchKernelGGL(cg1_rows_ui_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, rho_c, qp->st.alpha, 1, d.w_k, d.w_i, d.w_j,

@@ -14,6 +14,7 @@ enum Slot {  // device scalar slots (doubles)
 struct QpDev {
   // constant blocks
   double *F, *Ft, *S0, *S0t, *HS, *Hf, *Minv, *aug, *wrow;
+  double* MS;  // [2K][K]: [H_f^{-1} ; S0 H_f^{-1}]
   // fixed rows
   double *lf, *uf, *zf, *yf, *wf, *tf;
   // x-space vectors [K][C]
@@ -48,7 +49,7 @@ struct scp_qp {
 
 // scp_qp_fused.hip: one ADMM iteration with the column-local chains fused into column-block kernels
 // (K <= SCP_FUSED_MAX_K).  Same arithmetic as admm_iteration() in scp_qp.hip.
-constexpr int SCP_FUSED_MAX_K = 64;   // (4K + 4K-1) * 128 B of LDS tiles must stay below 64 KiB
+constexpr int SCP_FUSED_MAX_K = 50;   // (6K + 4K-1) * 128 B of LDS tiles must stay below 64 KiB
 constexpr int SCP_PART_CAP = 4096;  // capacity of each partial-sum array (column blocks of the fused path)
 int scp_qp_fused_iteration(scp_qp* qp, int* cg_count);
 // single-PCG-step pipeline (cg_iters == 1 and a non-empty working set): 4 launches per ADMM step

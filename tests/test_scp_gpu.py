@@ -212,3 +212,34 @@ def test_scp_two_ranks_share_one_gpu(tmp_path):
     s, traj = solve_gpu(40, 10.0, 0.2, 0.8, space, p0, pf, max_iterations=3)
     assert [i["iter"] for i in s.last_info["iterations"]] == np.load(tmp_path / "its_0.npy").tolist()
     np.testing.assert_allclose(a, traj["positions"], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("n,T,h,dim", [(1, 2.0, 0.2, 2), (2, 0.8, 0.2, 2), (1, 2.0, 0.5, 3), (3, 1.0, 0.5, 3)])
+def test_edge_sizes(n, T, h, dim):
+    """Smallest shapes: a single agent (no pairs at all), K = 3 time steps, 3-D with few agents."""
+    rng = np.random.default_rng(n * 10 + dim)
+    p0 = rng.uniform(2, 4, (n, dim)) + np.arange(n)[:, None] * 3.0
+    pf = p0 + rng.uniform(-0.1, 0.1, (n, dim))  # reachable within the jerk limit even at K = 3
+    space = [0.0] * dim + [20.0] * dim
+    s, traj = solve_gpu(n, T, h, 0.8, space, p0, pf, dim=dim)
+    prob = so.make_problem(n, T, h, 0.8, space, p0, pf)
+    out = qo.scp_solve(prob, 15, qo.Settings(max_iter=10000))
+    assert traj["positions"].shape == (n, prob.K, dim)
+    assert s.last_info["n_iterations"] == out["iterations"]
+    np.testing.assert_allclose(traj["positions"], out["positions"], rtol=0, atol=TOL)
+    rep = s.validate_solution()
+    assert rep["collision_free"] and rep["final_position_error"] < 3e-2
+
+
+def test_generic_path_large_K():
+    """K > 50 leaves the fused column-block kernels for the generic one-product-per-launch path (the reference's
+    compute-trajectories demo runs K = 500): same oracle, same tolerance."""
+    from path_planning.scenarios.position_generator import generate_positions
+
+    p0, pf = generate_positions(5, 0.8, seed=2)
+    s, traj = solve_gpu(5, 14.0, 0.2, 0.8, [0, 0, 20, 20], p0, pf, max_iterations=2)  # K = 70
+    prob = so.make_problem(5, 14.0, 0.2, 0.8, [0, 0, 20, 20], p0, pf)
+    assert prob.K == 70
+    out = qo.scp_solve(prob, 2, qo.Settings(max_iter=10000))
+    assert s.last_info["n_iterations"] == out["iterations"]
+    np.testing.assert_allclose(traj["positions"], out["positions"], rtol=0, atol=TOL)

@@ -611,6 +611,15 @@ __global__ __launch_bounds__(256) void cg1_rows_ui_kernel(int64_t nW, int64_t C,
 
 #define FUSED_LAUNCHED(qp) SCP_HIP_CHECK((qp)->ctx, hipGetLastError())
 
+// Tiles beyond 64 KiB of dynamic LDS (K > 50) need the limit raised once per kernel (gfx950: 160 KiB per workgroup).
+template <typename Kern>
+int allow_lds(scp_qp* qp, Kern kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return SCP_OK;
+  SCP_HIP_CHECK(qp->ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return SCP_OK;
+}
+
 }  // namespace
 
 int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
@@ -631,6 +640,12 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
   int fold = 0, fold_first = 0, fold_slot = SL_RZ0;
   const double* fold_part = part_rz;
 
+  {
+    int rc = allow_lds(qp, fused_pre_kernel, (size_t)(4 * K + Rf) * tile);
+    if (!rc) rc = allow_lds(qp, fused_cg_init_kernel, (size_t)(5 * K) * tile);
+    if (!rc) rc = allow_lds(qp, fused_post_kernel, (size_t)(2 * K + Rf) * tile);
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(fused_pre_kernel, cgrid, cblock, (size_t)(4 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.sigma,
                      has_rows, d.Ft, d.HS, d.Minv, d.wrow, d.x, d.zf, d.yf, d.rhs, Q, d.xt, d.G);
   FUSED_LAUNCHED(qp);
@@ -735,6 +750,11 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count) {
   const double rho_c = qp->rho * qp->st.rho_col_scale;
   if (!qp->cg1_ready) {
     int rc = scp_qp_cg1_prepare(qp);
+    if (rc) return rc;
+  }
+  {
+    int rc = allow_lds(qp, cg1_colA_kernel, (size_t)(6 * K + Rf) * tile);
+    if (!rc) rc = allow_lds(qp, cg1_post_kernel, (size_t)(2 * K + Rf) * tile);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(cg1_colA_kernel, cgrid, cblock, (size_t)(6 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.sigma, d.Ft,

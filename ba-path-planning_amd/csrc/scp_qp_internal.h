@@ -49,7 +49,7 @@ struct scp_qp {
 
 // scp_qp_fused.hip: one ADMM iteration with the column-local chains fused into column-block kernels
 // (K <= SCP_FUSED_MAX_K).  Same arithmetic as admm_iteration() in scp_qp.hip.
-constexpr int SCP_FUSED_MAX_K = 50;   // (6K + 4K-1) * 128 B of LDS tiles must stay below 64 KiB
+constexpr int SCP_FUSED_MAX_K = 120;  // (6K + 4K-1) * 128 B of LDS tiles <= 160 KiB (limit raised above 64 KiB)
 constexpr int SCP_PART_CAP = 4096;  // capacity of each partial-sum array (column blocks of the fused path)
 int scp_qp_fused_iteration(scp_qp* qp, int* cg_count);
 // single-PCG-step pipeline (cg_iters == 1 and a non-empty working set): 4 launches per ADMM step

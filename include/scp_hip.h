@@ -66,7 +66,7 @@ typedef struct scp_qp_settings {
   double adaptive_rho_tolerance; /* 5 */
   int32_t cg_iters;              /* 1: PCG steps per ADMM step (fixed count, warm started at x) */
   int32_t use_mfma;              /* 1: fused column-block kernels, every K-dimension product on
-                                    v_mfma_f64_16x16x4_f64 (K <= 64; larger K falls back to 2);
+                                    v_mfma_f64_16x16x4_f64 (K <= 120; larger K falls back to 2);
                                     2: one MFMA product per launch (generic path); 0: VALU products */
   double rho_col_scale;          /* 10: rho of the collision rows = rho * rho_col_scale (like OSQP's per-row rho,
                                     which the reference gets x 1e3 on equality rows only).  Measured at 1024 x 50:

@@ -231,15 +231,16 @@ def test_edge_sizes(n, T, h, dim):
     assert rep["collision_free"] and rep["final_position_error"] < 3e-2
 
 
-def test_generic_path_large_K():
-    """K > 50 leaves the fused column-block kernels for the generic one-product-per-launch path (the reference's
-    compute-trajectories demo runs K = 500): same oracle, same tolerance."""
+@pytest.mark.parametrize("T,K", [(14.0, 70), (26.0, 130)])
+def test_large_K_paths(T, K):
+    """K = 70: fused column-block kernels with more than 64 KiB of LDS tiles; K = 130 > 120: the generic
+    one-product-per-launch path (the reference's compute-trajectories demo runs K = 500).  Same oracle, same tolerance."""
     from path_planning.scenarios.position_generator import generate_positions
 
     p0, pf = generate_positions(5, 0.8, seed=2)
-    s, traj = solve_gpu(5, 14.0, 0.2, 0.8, [0, 0, 20, 20], p0, pf, max_iterations=2)  # K = 70
-    prob = so.make_problem(5, 14.0, 0.2, 0.8, [0, 0, 20, 20], p0, pf)
-    assert prob.K == 70
+    s, traj = solve_gpu(5, T, 0.2, 0.8, [0, 0, 20, 20], p0, pf, max_iterations=2)
+    prob = so.make_problem(5, T, 0.2, 0.8, [0, 0, 20, 20], p0, pf)
+    assert prob.K == K
     out = qo.scp_solve(prob, 2, qo.Settings(max_iter=10000))
     assert s.last_info["n_iterations"] == out["iterations"]
     np.testing.assert_allclose(traj["positions"], out["positions"], rtol=0, atol=TOL)

@@ -98,7 +98,7 @@ def test_linearize_vs_reference(ctx, golden_dir, name):
 
 
 @pytest.mark.parametrize("N,K,D,seed", [(2, 5, 2, 1), (7, 13, 2, 2), (33, 21, 3, 3), (96, 50, 2, 4), (65, 50, 3, 5),
-                                        (130, 17, 2, 6)])
+                                        (130, 17, 2, 6), (300, 7, 2, 7), (257, 5, 3, 8), (256, 4, 2, 9)])
 def test_linearize_vs_oracle_synthetic(ctx, N, K, D, seed):
     from path_planning import _hip
 
@@ -127,15 +127,16 @@ def test_linearize_vs_oracle_synthetic(ctx, N, K, D, seed):
     np.testing.assert_array_equal(w_l.cpu().numpy(), pp.l_rows().cpu().numpy()[r])
 
 
-def test_linearize_pair_range_shards(ctx):
-    """Sharded pair ranges (multi-GPU layout) tile the full pass exactly."""
+@pytest.mark.parametrize("N,K,cuts", [(41, 19, [0, 101, 102, 500]), (290, 5, [0, 1, 8191, 8193, 20000, 20001])])
+def test_linearize_pair_range_shards(ctx, N, K, cuts):
+    """Sharded pair ranges (multi-GPU layout) tile the full pass exactly (N = 290: the wave-segment kernel)."""
     from path_planning import _hip
 
-    prob, acc = synth(41, 19, 2, 11)
+    prob, acc = synth(N, K, 2, 11)
     pos, _ = so.kinematics(prob, acc)
     eta_o, l_o, dist_o = so.linearize_pairs(prob, pos)
     pairs = prob.pairs
-    cuts = [0, 101, 102, 500, pairs]
+    cuts = cuts + [pairs]
     got = []
     for a, b in zip(cuts[:-1], cuts[1:]):
         pp = _hip.PairPass(ctx, prob.N, prob.K, 2, prob.R, prob.h, a, b)
@@ -161,7 +162,7 @@ def test_degenerate_pair(ctx):
     np.testing.assert_allclose(pp.l_rows().cpu().numpy(), l_o, rtol=0, atol=1e-15)
 
 
-@pytest.mark.parametrize("N,K,D,seed", [(9, 12, 2, 21), (40, 50, 2, 22), (30, 25, 3, 23)])
+@pytest.mark.parametrize("N,K,D,seed", [(9, 12, 2, 21), (40, 50, 2, 22), (30, 25, 3, 23), (280, 6, 2, 24), (270, 3, 3, 25)])
 def test_collision_violations_pass(ctx, N, K, D, seed):
     from path_planning import _hip
 

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 // ----------------------------------------------------------------------------------------------------
 // context
@@ -478,6 +479,14 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
     }
   }
 
+  // Interior workgroups (all PAIR_ROWS rows inside the slice: all but the first and last of a time step) take the
+  // FULL instantiation, which carries no per-row validity masks, index clamps or scalar-store fallbacks.
+  const bool full = c0 >= 0 && c0 + PAIR_ROWS <= nq;
+  double* const eta_k = a.eta + slice0;  // wave-uniform bases + 32-bit lane offsets: saddr-form global accesses
+  double* const l_k = a.l + slice0;
+  const int o0 = (int)off0;
+  auto body = [&](auto full_tag) {
+  constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll 1
   for (int s0 = 0; s0 < PAIR_STEPS; s0 += PAIR_UNROLL) {
     double eta_v[PAIR_UNROLL][2][D];
@@ -491,8 +500,8 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
 #pragma unroll
     for (int u = 0; u < PAIR_UNROLL; ++u) {
       const int64_t off = off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS);
-      valid[u][0] = (off >= 0) && (off < nq);
-      valid[u][1] = (off + 1 >= 0) && (off + 1 < nq);
+      valid[u][0] = FULL || ((off >= 0) && (off < nq));
+      valid[u][1] = FULL || ((off + 1 >= 0) && (off + 1 < nq));
       pi_[u][0] = ci;
       pj_[u][0] = cj;
       int i1 = ci, j1 = cj;
@@ -500,29 +509,32 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
       pi_[u][1] = i1;
       pj_[u][1] = j1;
       pair_advance(ci, cj, N, 2 * PAIR_THREADS);
+      if (!FULL) {
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
-        if (!valid[u][e] || pi_[u][e] >= N - 1 || pj_[u][e] >= N || pj_[u][e] <= pi_[u][e]) {
-          valid[u][e] = false;
-          pi_[u][e] = 0;
-          pj_[u][e] = N > 1 ? 1 : 0;
-        }
+        for (int e = 0; e < 2; ++e)
+          if (!valid[u][e] || pi_[u][e] >= N - 1 || pj_[u][e] >= N || pj_[u][e] <= pi_[u][e]) {
+            valid[u][e] = false;
+            pi_[u][e] = 0;
+            pj_[u][e] = N > 1 ? 1 : 0;
+          }
+      }
     }
     uint32_t marked[PAIR_UNROLL];
     if (MODE == MODE_VIOLATIONS) {  // streaming reads of the compact rows, all issued before use
 #pragma unroll
       for (int u = 0; u < PAIR_UNROLL; ++u) {
         const int64_t lrA = slice0 + off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS);
+        const int o32 = o0 + (s0 + u) * (2 * PAIR_THREADS);
         // both rows of the step share one bitmap word (lrA is even); rows already in the working set stay out
         marked[u] = (valid[u][0] || valid[u][1]) ? (a.bitmap[(lrA + (valid[u][0] ? 0 : 1)) >> 5] >> (lrA & 31)) & 3u : 0u;
-        if (valid[u][0] && valid[u][1]) {
+        if (FULL || (valid[u][0] && valid[u][1])) {
 #pragma unroll
           for (int d = 0; d < D; ++d) {
-            const double2 t = *reinterpret_cast<const double2*>(a.eta + d * a.eta_stride + lrA);
+            const double2 t = *reinterpret_cast<const double2*>(eta_k + d * a.eta_stride + o32);
             ein[u][0][d] = t.x;
             ein[u][1][d] = t.y;
           }
-          const double2 t = *reinterpret_cast<const double2*>(a.l + lrA);
+          const double2 t = *reinterpret_cast<const double2*>(l_k + o32);
           lin_[u][0] = t.x;
           lin_[u][1] = t.y;
         } else {
@@ -601,11 +613,12 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
 #pragma unroll
       for (int u = 0; u < PAIR_UNROLL; ++u) {
         const int64_t lrA = slice0 + off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS);  // even by construction
-        if (valid[u][0] && valid[u][1]) {
+        const int o32 = o0 + (s0 + u) * (2 * PAIR_THREADS);
+        if (FULL || (valid[u][0] && valid[u][1])) {
 #pragma unroll
           for (int d = 0; d < D; ++d)
-            *reinterpret_cast<double2*>(a.eta + d * a.eta_stride + lrA) = make_double2(eta_v[u][0][d], eta_v[u][1][d]);
-          *reinterpret_cast<double2*>(a.l + lrA) = make_double2(l_v[u][0], l_v[u][1]);
+            *reinterpret_cast<double2*>(eta_k + d * a.eta_stride + o32) = make_double2(eta_v[u][0][d], eta_v[u][1][d]);
+          *reinterpret_cast<double2*>(l_k + o32) = make_double2(l_v[u][0], l_v[u][1]);
         } else {
 #pragma unroll
           for (int e = 0; e < 2; ++e)
@@ -633,6 +646,9 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
       }
     }
   }
+  };
+  if (full) body(std::true_type{});
+  else body(std::false_type{});
 
   // wavefront reductions, then one candidate per WORKGROUP; the global atomic is issued only when a relaxed
   // (L1-bypassing) read says the candidate would improve the result: same-address atomics retire at < 100 per

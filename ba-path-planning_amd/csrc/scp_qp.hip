@@ -884,6 +884,38 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
   return SCP_OK;
 }
 
+extern "C" int scp_qp_clone_state(scp_qp* dst, const scp_qp* src) {
+  if (!dst || !src) return SCP_ERR_INVALID;
+  scp_ctx* ctx = dst->ctx;
+  SCP_REQUIRE(ctx, dst->N == src->N && dst->K == src->K && dst->D == src->D && dst->h == src->h,
+              "qp_clone_state: shapes differ");
+  if (!src->reset_done) return scp_fail(ctx, SCP_ERR_STATE, "qp_clone_state: source has no state");
+  if (src->nW > dst->row_cap)
+    return scp_fail(ctx, SCP_ERR_CAPACITY, "qp_clone_state: %lld rows exceed the capacity %lld", (long long)src->nW,
+                    (long long)dst->row_cap);
+  hipStream_t s = ctx->stream;
+  const size_t nf = (size_t)src->Rf * src->C * sizeof(double), nx = (size_t)src->K * src->C * sizeof(double);
+  const size_t nw = (size_t)src->nW;
+  const QpDev &a = src->d, &b = dst->d;
+#define CP(field, bytes) SCP_HIP_CHECK(ctx, hipMemcpyAsync(b.field, a.field, (bytes), hipMemcpyDeviceToDevice, s))
+  CP(lf, nf); CP(uf, nf); CP(zf, nf); CP(yf, nf); CP(x, nx);
+  if (nw) {
+    CP(w_row, nw * sizeof(int64_t)); CP(w_k, nw * sizeof(int)); CP(w_i, nw * sizeof(int)); CP(w_j, nw * sizeof(int));
+    CP(w_eta, nw * src->D * sizeof(double)); CP(w_l, nw * sizeof(double)); CP(zc, nw * sizeof(double));
+    CP(yc, nw * sizeof(double));
+  }
+#undef CP
+  dst->nW = src->nW;
+  dst->rho = src->rho;
+  dst->st = src->st;
+  dst->problem_set = true;
+  dst->cg1_ready = false;
+  QP_CHECK(build_kkt(dst));
+  dst->reset_done = true;
+  SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // src's workspace may be released by the caller right after
+  return SCP_OK;
+}
+
 extern "C" int scp_qp_get_solution(scp_qp* qp, double* x_out) {
   if (!qp) return SCP_ERR_INVALID;
   SCP_REQUIRE(qp->ctx, x_out, "qp_get_solution: null pointer");

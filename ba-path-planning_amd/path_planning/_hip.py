@@ -60,7 +60,8 @@ EXPORTS = [
     "scp_kinematics", "scp_fixed_bounds", "scp_linearize_pairs", "scp_check_avoidance",
     "scp_collision_violations", "scp_gather_rows", "scp_rel_step", "scp_qp_default_settings",
     "scp_qp_workspace_bytes", "scp_qp_create", "scp_qp_destroy", "scp_qp_update_settings", "scp_qp_set_problem",
-    "scp_qp_reset", "scp_qp_add_rows", "scp_qp_solve", "scp_qp_get_solution", "scp_qp_get_duals", "scp_gemm_f64",
+    "scp_qp_reset", "scp_qp_add_rows", "scp_qp_solve", "scp_qp_clone_state", "scp_qp_get_solution",
+    "scp_qp_get_duals", "scp_gemm_f64",
 ]
 
 
@@ -111,6 +112,7 @@ def load_library():
     lib.scp_qp_reset.argtypes = [vp, vp]
     lib.scp_qp_add_rows.argtypes = [vp, i64, vp, vp, vp]
     lib.scp_qp_solve.argtypes = [vp, C.POINTER(QpInfo)]
+    lib.scp_qp_clone_state.argtypes = [vp, vp]
     lib.scp_qp_get_solution.argtypes = [vp, vp]
     lib.scp_qp_get_duals.argtypes = [vp, vp, vp]
     lib.scp_gemm_f64.argtypes = [vp, i32, i32, i32, i32, f64, vp, vp, f64, vp]
@@ -364,6 +366,11 @@ class QP:
             return
         self.ctx.check(self.ctx.lib.scp_qp_add_rows(self.h_qp, n, rows.data_ptr(), w_eta.data_ptr(), w_l.data_ptr()))
         self.n_rows += n
+
+    def take_state_of(self, other: "QP"):
+        """Continue `other`'s solve in this (larger) workspace."""
+        self.ctx.check(self.ctx.lib.scp_qp_clone_state(self.h_qp, other.h_qp))
+        self.n_rows = other.n_rows
 
     def solve(self):
         info = QpInfo()

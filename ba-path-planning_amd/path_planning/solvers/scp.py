@@ -12,7 +12,8 @@ Differences to the reference that a caller can observe (INTEGRATION.md has the f
   * ``_add_collision_constraints`` returns the compact form (eta, l) of the constraint rows instead of a
     2.6e9-non-zero CSC matrix; ``C_jerk/C_acc/C_vel/C_pos`` are not materialised (they stay None);
   * new keyword-only arguments: ``dim`` (2 or 3), ``device``, ``qp_settings``, ``working_set_margin``,
-    ``feasibility_tol``, ``verbose``, ``rank``/``world_size``/``group`` (agent-sharded multi-GPU).
+    ``feasibility_tol``, ``max_rounds``, ``refresh_feasibility``, ``qp_row_capacity``, ``verbose``,
+    ``rank``/``world_size``/``group`` (agent-sharded multi-GPU).
 """
 from __future__ import annotations
 
@@ -40,6 +41,7 @@ class SCP:
         feasibility_tol=1e-6,
         max_rounds=20,
         refresh_feasibility=False,
+        qp_row_capacity=None,
         verbose=True,
         rank=0,
         world_size=1,
@@ -85,6 +87,7 @@ class SCP:
         self.feasibility_tol = float(feasibility_tol)
         self.max_rounds = int(max_rounds)
         self.refresh_feasibility = bool(refresh_feasibility)
+        self._qp_row_capacity = qp_row_capacity  # initial working-set capacity (grows on demand)
         self._qp_overrides = dict(qp_settings or {})
         self.shard = Shard(self.N, rank, world_size, group)
         if device is None:
@@ -161,7 +164,7 @@ class SCP:
         if self._qp is None:
             known = {k for k, _ in _hip.QpSettings._fields_}
             st = _hip.default_settings(**{k: v for k, v in self._qp_overrides.items() if k in known})
-            self._qp = _hip.QP(self._ctx, self.N, self.K, self.D, self.h, st)
+            self._qp = _hip.QP(self._ctx, self.N, self.K, self.D, self.h, st, row_capacity=self._qp_row_capacity)
         return self._qp
 
     def _ensure_pairs(self):
@@ -170,16 +173,20 @@ class SCP:
             self._pairs = _hip.PairPass(self._ctx, self.N, self.K, self.D, self.R, self.h, q0, q1)
         return self._pairs
 
-    def _grow_qp(self, need):
-        """Working set outgrew the QP's row capacity: rebuild the solver with room for `need` rows."""
+    def _grow_qp(self, need, keep_state=False):
+        """Working set outgrew the QP's row capacity: move the solver to a workspace with room for `need` rows
+        (keep_state: iterate, duals, working set and rho travel along, so the solve continues unchanged)."""
         old = self._qp
         cap = int(min(self.K * self.shard.pairs, max(need, 2 * old.row_capacity)))
-        st = old.settings
+        new = _hip.QP(self._ctx, self.N, self.K, self.D, self.h, old.settings, row_capacity=cap)
+        if keep_state:
+            new.take_state_of(old)
+        else:
+            p0, v0, pf, vf = self._states()
+            new.set_problem(self._limits(), self._space(), p0, v0, pf, vf)
         old.close()
-        self._qp = _hip.QP(self._ctx, self.N, self.K, self.D, self.h, st, row_capacity=cap)
-        p0, v0, pf, vf = self._states()
-        self._qp.set_problem(self._limits(), self._space(), p0, v0, pf, vf)
-        return self._qp
+        self._qp = new
+        return new
 
     # ------------------------------------------------------------------------------------------------
     # a1: SCP loop (scp.py:131-180)
@@ -334,7 +341,6 @@ class SCP:
         w_eta, w_l = pp.gather(rows)
         rows, w_eta, w_l = self.shard.allgather_rows(rows, w_eta, w_l)
 
-        all_rows, all_eta, all_l = [rows], [w_eta], [w_l]
         qp.reset(acc)
         try:
             qp.add_rows(rows, w_eta, w_l)
@@ -368,19 +374,14 @@ class SCP:
             added.append(int(new_rows.numel()))
             if new_rows.numel() == 0 or used >= max_iter:
                 break
-            all_rows.append(new_rows), all_eta.append(n_eta), all_l.append(n_l)
             try:
                 qp.add_rows(new_rows, n_eta, n_l)
             except _hip.HipError as e:
                 if e.code != _hip.SCP_ERR_CAPACITY:
                     raise
-                # restart this QP with a larger solver and every row collected so far
-                import torch
-
-                rows_cat, eta_cat, l_cat = torch.cat(all_rows), torch.cat(all_eta), torch.cat(all_l)
-                qp = self._grow_qp(int(rows_cat.numel()))
-                qp.reset(x)
-                qp.add_rows(rows_cat, eta_cat, l_cat)
+                # continue in a larger workspace: the state of the solve travels along
+                qp = self._grow_qp(qp.n_rows + int(new_rows.numel()), keep_state=True)
+                qp.add_rows(new_rows, n_eta, n_l)
 
         self._last_qp_info = dict(info, **total, rounds=len(added), added=added)
         if info["status_val"] not in (1, 2):  # scp.py:446-447

@@ -175,6 +175,10 @@ int scp_qp_reset(scp_qp* qp, const double* x0);
 /* append working rows (global ids; eta AoS [n][D]; lower bounds); z = max(A x, l), y = 0 */
 int scp_qp_add_rows(scp_qp* qp, int64_t n, const int64_t* rows, const double* w_eta, const double* w_l);
 int scp_qp_solve(scp_qp* qp, scp_qp_info* info /*[host]*/);
+/* Move a QP to a larger workspace: dst (same N, K, D, h; row_capacity >= src's working rows) takes over the
+ * problem bounds, iterate, duals, working set and rho of src, so a solve can continue after its working set outgrew
+ * the capacity it was created with. */
+int scp_qp_clone_state(scp_qp* dst, const scp_qp* src);
 int scp_qp_get_solution(scp_qp* qp, double* x_out /*[N][K][D]*/);
 /* duals: y_fixed in the reference stacking order (N*D*(4K-1)), y_col per working row (may be NULL) */
 int scp_qp_get_duals(scp_qp* qp, double* y_fixed, double* y_col);

@@ -163,6 +163,29 @@ def test_validate_solution_and_refresh_feasibility():
     assert s2.validate_solution()["min_pair_distance"] >= 0.8 - 0.011 or not s2.last_info["converged"]
 
 
+def test_capacity_growth_paths():
+    """Working-set capacity of the QP and the selection list of the pairwise pass start tiny and must grow on
+    demand (restart with every row collected so far) without changing the result."""
+    from path_planning import _hip
+
+    p0, pf = ref_scenario(10, 7)
+    ref, t_ref = solve_gpu(10, 10.0, 0.2, 0.8, [0, 0, 20, 20], p0, pf, max_iterations=3)
+    small, t_small = solve_gpu(10, 10.0, 0.2, 0.8, [0, 0, 20, 20], p0, pf, max_iterations=3, qp_row_capacity=4)
+    assert small._qp.row_capacity > 4
+    assert [i["working_rows"] for i in small.last_info["iterations"]] == [i["working_rows"] for i in ref.last_info["iterations"]]
+    np.testing.assert_allclose(t_small["positions"], t_ref["positions"], rtol=0, atol=TOL)
+    # selection list of the pairwise pass: capacity 8 -> grows, same (sorted) rows
+    ctx = ref._ctx
+    prob = so.make_problem(10, 10.0, 0.2, 0.8, [0, 0, 20, 20], p0, pf)
+    pos = ctx.tensor(t_ref["positions"])
+    big = _hip.PairPass(ctx, 10, prob.K, 2, 0.8, 0.2)
+    tiny = _hip.PairPass(ctx, 10, prob.K, 2, 0.8, 0.2, sel_cap=8)
+    rows_big, _, _ = big.linearize(pos, ctx.tensor(prob.p0), ctx.tensor(prob.v0), 2.0)
+    rows_tiny, _, _ = tiny.linearize(pos, ctx.tensor(prob.p0), ctx.tensor(prob.v0), 2.0)
+    assert rows_big.numel() > 8 and tiny.sel_cap >= rows_big.numel()
+    np.testing.assert_array_equal(rows_tiny.cpu().numpy(), rows_big.cpu().numpy())
+
+
 def test_plots_headless(tmp_path):
     p0, pf = ref_scenario(4, 1)
     s, _ = solve_gpu(4, 10.0, 0.5, 0.8, [0, 0, 20, 20], p0, pf, max_iterations=1)

@@ -297,24 +297,6 @@ __global__ void pair_stats_init_kernel(scp_pair_stats* s) {
   s->max_violation = -__longlong_as_double(0x7FF0000000000000LL);
 }
 
-// wave-aggregated append of the lanes with `sel` to list[] (arrival order), returns nothing; rows beyond
-// `cap` are counted but not stored.
-__device__ inline void wave_append(bool sel, int64_t value, int64_t* list, int64_t cap,
-                                   unsigned long long* counter) {
-  const unsigned long long mask = __ballot(sel);
-  if (mask == 0) return;
-  const int lane = threadIdx.x & 63;
-  const int leader = __ffsll((long long)mask) - 1;
-  unsigned long long base = 0;
-  if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(mask));
-  base = __shfl(base, leader);
-  if (sel) {
-    const unsigned long long below = mask & ((1ULL << lane) - 1ULL);
-    const int64_t idx = (int64_t)(base + __popcll(below));
-    if (idx < cap) list[idx] = value;
-  }
-}
-
 __device__ inline double wave_min(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));

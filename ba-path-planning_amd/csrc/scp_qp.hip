@@ -862,6 +862,10 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
         const double dual = rd / fmax(nd, 1e-10);
         double nr = qp->rho * std::sqrt(prim / fmax(dual, 1e-10));
         nr = fmin(fmax(nr, 1e-6), 1e6);
+        // snapped to a geometric grid (steps of 2^(1/4)): the estimate is a ratio of small residuals; without the
+        // grid 1e-13 of fp noise (atomics order, MFMA vs scalar sums) becomes a percent-level difference in rho and
+        // an iterate path that differs from the oracle's at the 1e-4 level although both are valid solutions
+        nr = std::exp2(std::round(4.0 * std::log2(nr)) / 4.0);
         if (nr > qp->rho * st.adaptive_rho_tolerance || nr < qp->rho / st.adaptive_rho_tolerance) {
           qp->rho = nr;
           QP_CHECK(build_kkt(qp));

@@ -418,6 +418,10 @@ def admm_structured(prob: so.Problem, eta=None, l_col=None, dist=None, x0=None, 
                     prim = rp_ / max(nAx, nz, 1e-10)
                     dual = rd_ / max(nPx, nATy, 1e-10)
                     new = min(max(rho * np.sqrt(prim / max(dual, 1e-10)), 1e-6), 1e6)
+                    # snapped to a geometric grid (steps of 2^(1/4)): the estimate is a ratio of small residuals, so
+                    # 1e-13 of fp noise would otherwise become a percent-level difference in rho and send two
+                    # implementations of the same algorithm down visibly different (equally valid) iterate paths
+                    new = float(2.0 ** (np.round(4.0 * np.log2(new)) / 4.0))
                     if new > rho * st.adaptive_rho_tolerance or new < rho / st.adaptive_rho_tolerance:
                         rho = new
                         rvv, rpp, M, Hf = build(rho)

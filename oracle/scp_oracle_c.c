@@ -523,6 +523,7 @@ int oc_admm(const oc_problem* P, const double* eta, const double* l_col, const d
           const double prim = rp / dmax(dmax(nAx, nz), 1e-10), dual = rd / dmax(dmax(nPx, nATy), 1e-10);
           double nr = rho * sqrt(prim / dmax(dual, 1e-10));
           nr = dmin(dmax(nr, 1e-6), 1e6);
+          nr = exp2(round(4.0 * log2(nr)) / 4.0); /* geometric grid, see qp_oracle.py */
           if (nr > rho * st->adaptive_rho_tolerance || nr < rho / st->adaptive_rho_tolerance) {
             rho = nr;
             build_hf(K, h, st->sigma, rho, st->rho_eq_scale, Hf);

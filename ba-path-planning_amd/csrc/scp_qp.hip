@@ -454,6 +454,14 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.hpf = c.take<double>(nx);
   d.dyf = c.take<double>(nf);
   d.dyc = c.take<double>((size_t)cap);
+  const size_t ncell = (size_t)(C / D) * K;
+  d.cell_ptr = c.take<int>(ncell + 1);
+  d.cell_cur = c.take<int>(ncell);
+  d.ent_code = c.take<int>((size_t)2 * cap);
+  d.coef = c.take<double>((size_t)2 * cap * D);
+  d.gval = c.take<double>((size_t)2 * cap);
+  d.pos_i = c.take<int>((size_t)cap);
+  d.pos_j = c.take<int>((size_t)cap);
   return c.off;
 }
 
@@ -613,7 +621,8 @@ int residuals(scp_qp* qp, bool with_dy) {
       hipLaunchKernelGGL(resid_rows_kernel<3>, dim3(blocks), dim3(256), 0, s, qp->nW, C, d.w_k, d.w_i, d.w_j, d.w_eta,
                          d.HQ + nx, d.zc, d.scal);
     QP_LAUNCHED(qp);
-    QP_CHECK(row_scatter<ROW_Y>(qp, nullptr));
+    if (qp->csr_valid) QP_CHECK(scp_qp_csr_scatter(qp, 1, nullptr));
+    else QP_CHECK(row_scatter<ROW_Y>(qp, nullptr));
     QP_CHECK(gemm(qp, K, K, 1.0, d.S0t, d.G, 1.0, d.rhs));
   }
   hipLaunchKernelGGL(resid_dual_kernel, dim3(128), dim3(256), 0, s, nx, d.x, d.rhs, d.scal);
@@ -633,7 +642,8 @@ int certificate_atdy(scp_qp* qp) {
   SCP_HIP_CHECK(ctx, hipMemsetAsync(d.scal + SL_NATDY, 0, sizeof(double), s));
   QP_CHECK(gemm(qp, K, Rf, 1.0, d.Ft, d.dyf, 0.0, d.rhs));
   if (qp->nW > 0) {
-    QP_CHECK(row_scatter<ROW_VEC>(qp, nullptr, d.dyc));
+    if (qp->csr_valid) QP_CHECK(scp_qp_csr_scatter(qp, 2, d.dyc));
+    else QP_CHECK(row_scatter<ROW_VEC>(qp, nullptr, d.dyc));
     QP_CHECK(gemm(qp, K, K, 1.0, d.S0t, d.G, 1.0, d.rhs));
   }
   hipLaunchKernelGGL(max_abs_kernel, dim3(128), dim3(256), 0, s, nx, d.rhs, d.scal + SL_NATDY);
@@ -699,6 +709,7 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
   qp->row_cap = row_capacity;
   qp->nW = 0;
   qp->problem_set = qp->reset_done = false;
+  qp->cg1_ready = qp->csr_valid = false;
   qp->rho = s->rho;
   carve(qp->d, workspace, K, qp->C, row_capacity, D);
   if (hipHostMalloc(&qp->h_scal, SL_COUNT * sizeof(double)) != hipSuccess) {
@@ -783,6 +794,7 @@ extern "C" int scp_qp_reset(scp_qp* qp, const double* x0) {
   qp->nW = 0;
   qp->rho = qp->st.rho;
   qp->cg1_ready = false;
+  qp->csr_valid = false;
   QP_CHECK(build_kkt(qp));
   qp->reset_done = true;
   return SCP_OK;
@@ -805,6 +817,7 @@ extern "C" int scp_qp_add_rows(scp_qp* qp, int64_t n, const int64_t* rows, const
   QP_LAUNCHED(qp);
   qp->nW += n;
   qp->cg1_ready = false;
+  qp->csr_valid = false;
   return SCP_OK;
 }
 
@@ -914,6 +927,7 @@ extern "C" int scp_qp_clone_state(scp_qp* dst, const scp_qp* src) {
   dst->st = src->st;
   dst->problem_set = true;
   dst->cg1_ready = false;
+  dst->csr_valid = false;
   QP_CHECK(build_kkt(dst));
   dst->reset_done = true;
   SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // src's workspace may be released by the caller right after

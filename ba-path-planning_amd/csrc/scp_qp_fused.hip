@@ -452,7 +452,9 @@ __global__ __launch_bounds__(FT) void cg1_colA_kernel(int K, int Rf, int64_t C, 
                                                        const double* __restrict__ S0t, const double* __restrict__ MS,
                                                        const double* __restrict__ wrow, const double* __restrict__ x,
                                                        const double* __restrict__ zf, const double* __restrict__ yf,
-                                                       double* __restrict__ G, double* __restrict__ p,
+                                                       int N, int D, const int* __restrict__ cell_ptr,
+                                                       const double* __restrict__ coef,
+                                                       const double* __restrict__ gval, double* __restrict__ p,
                                                        double* __restrict__ Qp, double* __restrict__ part_rz) {
   // Two MFMA phases.  A: four independent products side by side on four wave groups -- F^T W split in two halves
   // of its inner dimension, H_f x, S0^T G.  B: [p ; Qp] = [Minv ; S0 Minv] r  (H_f p = r needs no product, so
@@ -467,14 +469,26 @@ __global__ __launch_bounds__(FT) void cg1_colA_kernel(int K, int Rf, int64_t C, 
   double* T3 = T2 + K * CB;         // [K][16]    S0^T G
   const int64_t c0 = (int64_t)blockIdx.x * CB;
   tile_load(X, x, K, C, c0);
-  tile_load(Gt, G, K, C, c0);
+  // G = A_W^T g for this block's (time step, agent) cells, gathered from the incidence lists in a fixed order:
+  // deterministic, no atomics, no G slab
+  for (int e = threadIdx.x; e < K * CB; e += FT) {
+    const int k = e >> 4, c = e & 15;
+    double acc = 0.0;
+    if (c0 + c < C) {
+      const int col = (int)(c0 + c);
+      const int agent = col / D, d = col - agent * D;
+      const int cell = k * N + agent;
+      const int t1 = cell_ptr[cell + 1];
+      for (int t = cell_ptr[cell]; t < t1; ++t) acc += coef[(size_t)t * D + d] * gval[t];
+    }
+    Gt[e] = acc;
+  }
   for (int e = threadIdx.x; e < Rf * CB; e += FT) {
     const int r = e >> 4, c = e & 15;
     const int64_t g = (int64_t)r * C + c0 + c;
     W[e] = (c0 + c < C) ? rho * wrow[r] * zf[g] - yf[g] : 0.0;
   }
   __syncthreads();
-  tile_zero_global(G, K, C, c0);
   const int half = ((Rf / 2) + 3) & ~3;
   wg_mm_range<false>(Ft, K, Rf, 0, half, W, T1, 0, 4);
   wg_mm_range<false>(Ft, K, Rf, half, Rf, W, T1b, 4, 4);
@@ -570,15 +584,16 @@ __global__ __launch_bounds__(FT) void cg1_post_kernel(int K, int Rf, int64_t C, 
   }
 }
 
-// update = 1: z, y of the collision rows from Qt (= S0 x~); then the scatter of the NEXT x-update's right-hand
-// side and H x:  G += eta (rho zc - yc - rho eta.dQx)
+// update = 1: z, y of the collision rows from Qt (= S0 x~); then the row values of the NEXT x-update's right-hand
+// side and H x:  g = rho zc - yc - rho eta.dQx  (A_W^T g is gathered by colA)
 template <int D>
 __global__ __launch_bounds__(256) void cg1_rows_ui_kernel(int64_t nW, int64_t C, double rho, double alpha, int update,
                                                            const int* __restrict__ wk, const int* __restrict__ wi,
                                                            const int* __restrict__ wj, const double* __restrict__ weta,
                                                            const double* __restrict__ wl, const double* __restrict__ Qt,
                                                            const double* __restrict__ Qx, double* __restrict__ zc,
-                                                           double* __restrict__ yc, double* __restrict__ G) {
+                                                           double* __restrict__ yc, const int* __restrict__ pos_i,
+                                                           const int* __restrict__ pos_j, double* __restrict__ gval) {
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= nW) return;
   const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
@@ -601,12 +616,8 @@ __global__ __launch_bounds__(256) void cg1_rows_ui_kernel(int64_t nW, int64_t C,
     zc[n] = z;
   }
   const double g = (rho * z - y) - rho * ax;
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    const double c = e[d] * g;
-    atomicAdd(G + bi + d, c);
-    atomicAdd(G + bj + d, -c);
-  }
+  gval[pos_i[n]] = g;  // the column kernels gather  sum coef * gval  per (time step, agent) cell
+  gval[pos_j[n]] = g;
 }
 
 #define FUSED_LAUNCHED(qp) SCP_HIP_CHECK((qp)->ctx, hipGetLastError())
@@ -720,14 +731,17 @@ int scp_qp_cg1_prepare(scp_qp* qp) {
   const double rho_c = qp->rho * qp->st.rho_col_scale;
   int rc = scp_launch_gemm(qp->ctx, 1, K, K, (int)C, 1.0, d.S0, d.x, 0.0, Qx);
   if (rc) return rc;
-  SCP_HIP_CHECK(qp->ctx, hipMemsetAsync(d.G, 0, nx * sizeof(double), s));
+  if (!qp->csr_valid) {
+    rc = scp_qp_csr_build(qp);
+    if (rc) return rc;
+  }
   const dim3 rgrid((unsigned)((qp->nW + 255) / 256)), rblock(256);
   if (qp->D == 2)
     hipLaunchKernelGGL(cg1_rows_ui_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, rho_c, qp->st.alpha, 0, d.w_k, d.w_i,
-                       d.w_j, d.w_eta, d.w_l, d.HQ, Qx, d.zc, d.yc, d.G);
+                       d.w_j, d.w_eta, d.w_l, d.HQ, Qx, d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
   else
     hipLaunchKernelGGL(cg1_rows_ui_kernel<3>, rgrid, rblock, 0, s, qp->nW, C, rho_c, qp->st.alpha, 0, d.w_k, d.w_i,
-                       d.w_j, d.w_eta, d.w_l, d.HQ, Qx, d.zc, d.yc, d.G);
+                       d.w_j, d.w_eta, d.w_l, d.HQ, Qx, d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
   FUSED_LAUNCHED(qp);
   qp->cg1_ready = true;
   return SCP_OK;
@@ -758,7 +772,7 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count) {
     if (rc) return rc;
   }
   hipLaunchKernelGGL(cg1_colA_kernel, cgrid, cblock, (size_t)(6 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.sigma, d.Ft,
-                     d.HS, d.S0t, d.MS, d.wrow, d.x, d.zf, d.yf, d.G, d.p, Qp, part_rz);
+                     d.HS, d.S0t, d.MS, d.wrow, d.x, d.zf, d.yf, qp->N, qp->D, d.cell_ptr, d.coef, d.gval, d.p, Qp, part_rz);
   FUSED_LAUNCHED(qp);
   if (qp->D == 2)
     hipLaunchKernelGGL(cg1_rows_sq_kernel<2>, dim3(SQ_BLOCKS), rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
@@ -772,11 +786,156 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count) {
   FUSED_LAUNCHED(qp);
   if (qp->D == 2)
     hipLaunchKernelGGL(cg1_rows_ui_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, rho_c, qp->st.alpha, 1, d.w_k, d.w_i, d.w_j,
-                       d.w_eta, d.w_l, Qt, Qx, d.zc, d.yc, d.G);
+                       d.w_eta, d.w_l, Qt, Qx, d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
   else
     hipLaunchKernelGGL(cg1_rows_ui_kernel<3>, rgrid, rblock, 0, s, qp->nW, C, rho_c, qp->st.alpha, 1, d.w_k, d.w_i, d.w_j,
-                       d.w_eta, d.w_l, Qt, Qx, d.zc, d.yc, d.G);
+                       d.w_eta, d.w_l, Qt, Qx, d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
   FUSED_LAUNCHED(qp);
   ++*cg_count;
+  return SCP_OK;
+}
+
+// =====================================================================================================
+// Incidence lists of the working rows per (time step, agent) cell: the deterministic replacement of the atomic
+// row scatter.  Built once per change of the working set (count, scan, fill, sort inside the cells, finish).
+// =====================================================================================================
+namespace {
+
+__global__ __launch_bounds__(256) void csr_count_kernel(int64_t nW, int N, const int* __restrict__ wk,
+                                                         const int* __restrict__ wi, const int* __restrict__ wj,
+                                                         int* __restrict__ cnt) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= nW) return;
+  atomicAdd(cnt + wk[n] * N + wi[n], 1);  // integer counts: order independent
+  atomicAdd(cnt + wk[n] * N + wj[n], 1);
+}
+
+// exclusive scan of cnt[0..ncell) into ptr (in place: cnt and ptr are the same array), cursors = ptr
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int ncell, int* __restrict__ ptr, int* __restrict__ cur) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b0 = 0; b0 < ncell; b0 += 1024) {
+    const int c = b0 + threadIdx.x;
+    const int v = c < ncell ? ptr[c] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = carry_s;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    if (c < ncell) {
+      ptr[c] = base + incl - v;
+      cur[c] = base + incl - v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = base + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ptr[ncell] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void csr_fill_kernel(int64_t nW, int N, const int* __restrict__ wk,
+                                                        const int* __restrict__ wi, const int* __restrict__ wj,
+                                                        int* __restrict__ cur, int* __restrict__ ent) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= nW) return;
+  ent[atomicAdd(cur + wk[n] * N + wi[n], 1)] = (int)(2 * n);
+  ent[atomicAdd(cur + wk[n] * N + wj[n], 1)] = (int)(2 * n + 1);
+}
+
+// entries of a cell arrive in atomic order: sort them (ascending code) so that every sum has a fixed order
+__global__ __launch_bounds__(256) void csr_sort_kernel(int ncell, const int* __restrict__ ptr, int* __restrict__ ent) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncell) return;
+  const int b = ptr[c], e = ptr[c + 1];
+  for (int i = b + 1; i < e; ++i) {
+    const int v = ent[i];
+    int j = i - 1;
+    while (j >= b && ent[j] > v) {
+      ent[j + 1] = ent[j];
+      --j;
+    }
+    ent[j + 1] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void csr_finish_kernel(int64_t nent, int D, const int* __restrict__ ent,
+                                                          const double* __restrict__ weta, double* __restrict__ coef,
+                                                          int* __restrict__ pos_i, int* __restrict__ pos_j) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= nent) return;
+  const int code = ent[t];
+  const int n = code >> 1, side = code & 1;
+  for (int d = 0; d < D; ++d) coef[t * D + d] = side ? -weta[(int64_t)n * D + d] : weta[(int64_t)n * D + d];
+  if (side) pos_j[n] = (int)t;
+  else pos_i[n] = (int)t;
+}
+
+// row values for the residual / certificate scatters
+__global__ __launch_bounds__(256) void csr_rowval_kernel(int64_t nW, int mode, double rho, const double* __restrict__ zc,
+                                                          const double* __restrict__ yc, const double* __restrict__ vec,
+                                                          const int* __restrict__ pos_i, const int* __restrict__ pos_j,
+                                                          double* __restrict__ gval) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= nW) return;
+  const double g = mode == 0 ? rho * zc[n] - yc[n] : (mode == 1 ? yc[n] : vec[n]);
+  gval[pos_i[n]] = g;
+  gval[pos_j[n]] = g;
+}
+
+// G[k][col] = sum over the cell's entries of coef * gval
+__global__ __launch_bounds__(256) void csr_gather_kernel(int K, int N, int D, const int* __restrict__ ptr,
+                                                          const double* __restrict__ coef,
+                                                          const double* __restrict__ gval, double* __restrict__ G) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t C = (int64_t)N * D;
+  if (t >= C * K) return;
+  const int k = (int)(t / C), col = (int)(t % C);
+  const int agent = col / D, d = col - agent * D;
+  const int cell = k * N + agent;
+  double acc = 0.0;
+  const int t1 = ptr[cell + 1];
+  for (int e = ptr[cell]; e < t1; ++e) acc += coef[(size_t)e * D + d] * gval[e];
+  G[t] = acc;
+}
+
+}  // namespace
+
+int scp_qp_csr_build(scp_qp* qp) {
+  const QpDev& d = qp->d;
+  hipStream_t s = qp->ctx->stream;
+  const int ncell = qp->N * qp->K;
+  SCP_REQUIRE(qp->ctx, 2 * qp->nW < 0x3FFFFFFF, "csr_build: too many working rows for 32-bit entry codes");
+  SCP_HIP_CHECK(qp->ctx, hipMemsetAsync(d.cell_ptr, 0, (size_t)(ncell + 1) * sizeof(int), s));
+  if (qp->nW > 0) {
+    const dim3 rgrid((unsigned)((qp->nW + 255) / 256));
+    hipLaunchKernelGGL(csr_count_kernel, rgrid, dim3(256), 0, s, qp->nW, qp->N, d.w_k, d.w_i, d.w_j, d.cell_ptr);
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, ncell, d.cell_ptr, d.cell_cur);
+    hipLaunchKernelGGL(csr_fill_kernel, rgrid, dim3(256), 0, s, qp->nW, qp->N, d.w_k, d.w_i, d.w_j, d.cell_cur, d.ent_code);
+    hipLaunchKernelGGL(csr_sort_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, ncell, d.cell_ptr, d.ent_code);
+    hipLaunchKernelGGL(csr_finish_kernel, dim3((unsigned)((2 * qp->nW + 255) / 256)), dim3(256), 0, s, 2 * qp->nW, qp->D,
+                       d.ent_code, d.w_eta, d.coef, d.pos_i, d.pos_j);
+    FUSED_LAUNCHED(qp);
+  }
+  qp->csr_valid = true;
+  return SCP_OK;
+}
+
+int scp_qp_csr_scatter(scp_qp* qp, int mode, const double* vec) {
+  const QpDev& d = qp->d;
+  hipStream_t s = qp->ctx->stream;
+  const int64_t nx = (int64_t)qp->K * qp->C;
+  hipLaunchKernelGGL(csr_rowval_kernel, dim3((unsigned)((qp->nW + 255) / 256)), dim3(256), 0, s, qp->nW, mode,
+                     qp->rho * qp->st.rho_col_scale, d.zc, d.yc, vec, d.pos_i, d.pos_j, d.gval);
+  hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, s, qp->K, qp->N, qp->D,
+                     d.cell_ptr, d.coef, d.gval, d.G);
+  FUSED_LAUNCHED(qp);
   return SCP_OK;
 }

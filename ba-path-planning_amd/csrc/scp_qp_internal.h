@@ -30,6 +30,13 @@ struct QpDev {
   double* hpf;    // [K][C]: H_f p of the fused PCG
   double* dyf;    // [Rf][C]: snapshot of y_f, then delta-y (primal infeasibility certificate)
   double* dyc;    // [cap]  : same for the working rows
+  // deterministic row -> column transfer (single-step pipeline): incidence lists per (time step, agent) cell
+  int* cell_ptr;  // [N*K + 1] exclusive offsets into the entry arrays
+  int* cell_cur;  // [N*K]     fill cursors (build time)
+  int* ent_code;  // [2 cap]   2 n + side, sorted inside every cell (side 0: agent i, +eta; side 1: agent j, -eta)
+  double* coef;   // [2 cap][D] signed eta of the entry
+  double* gval;   // [2 cap]   per-entry row value, written by the row kernels (no atomics)
+  int *pos_i, *pos_j;  // [cap] entry positions of row n
 };
 
 struct scp_qp {
@@ -40,7 +47,8 @@ struct scp_qp {
   scp_qp_settings st;
   int64_t row_cap, nW;
   bool problem_set, reset_done;
-  bool cg1_ready;  // carried state (Qx, G) of the single-step pipeline matches (x, zc, yc, rho)
+  bool cg1_ready;  // carried state (Qx, gval) of the single-step pipeline matches (x, zc, yc, rho)
+  bool csr_valid;  // incidence lists match the working set
   double rho;
   QpDev d;
   double* h_scal;  // pinned
@@ -54,3 +62,7 @@ constexpr int SCP_PART_CAP = 4096;  // capacity of each partial-sum array (colum
 int scp_qp_fused_iteration(scp_qp* qp, int* cg_count);
 // single-PCG-step pipeline (cg_iters == 1 and a non-empty working set): 4 launches per ADMM step
 int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count);
+// Deterministic A_W^T g into the G slab (valid incidence lists required): mode 0: g = rho_c zc - yc, 1: g = yc,
+// 2: g = vec[n].  Two launches, no atomics.
+int scp_qp_csr_scatter(scp_qp* qp, int mode, const double* vec);
+int scp_qp_csr_build(scp_qp* qp);

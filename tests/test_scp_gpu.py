@@ -269,16 +269,19 @@ def test_large_K_paths(T, K):
     np.testing.assert_allclose(traj["positions"], out["positions"], rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("cg", [1, 2])
 @pytest.mark.parametrize("kind,n,seed", [("ref", 6, 11), ("ref", 8, 12), ("ref", 12, 13), ("ref", 16, 14),
                                          ("grid", 25, 15), ("grid", 36, 16), ("grid3d", 27, 17)])
-def test_scp_sweep_vs_oracle(kind, n, seed):
+def test_scp_sweep_vs_oracle(kind, n, seed, cg):
     """Full solves on more scenarios (reference generator and grid-swap, 2-D and 3-D) against the CPU oracle.
 
-    Tolerance: the ADMM termination tolerance, not fp64 round-off.  Some of these QPs are nearly degenerate (several
-    consecutive time steps of one pair active): 300 ADMM steps turn the 1e-16 differences between two summation
-    orders (fp64 atomics on the GPU, numpy on the CPU, even two GPU runs) into 1e-4 differences of two equally valid
-    eps = 1e-3 solutions, and a termination check can fall 25 steps later.  The pinned cases of
-    test_scp_matches_oracle (no such QP) agree to 1e-7."""
+    cg = 2 PCG steps per ADMM step: GPU and oracle agree iterate for iterate (same counts, waypoints to 1e-6).
+    cg = 1 (the default, twice as fast): the ADMM map with a single inexact x-update step is not contractive
+    during the transient -- on nearly degenerate QPs (one pair active over consecutive steps) it amplifies the
+    1e-13 difference between two summation orders (numpy vs MFMA) by up to 1e7 before both iterates converge to
+    the same solution -- so the two implementations may stop 25 steps apart at two equally valid eps = 1e-3
+    solutions: the tolerance there is the ADMM termination tolerance.  (tools/debug_qp.py shows the growth; the GPU
+    itself is deterministic run to run.)"""
     from path_planning.scenarios.position_generator import generate_grid_swap
 
     dim = 3 if kind == "grid3d" else 2
@@ -287,14 +290,18 @@ def test_scp_sweep_vs_oracle(kind, n, seed):
         space = [0, 0, 20, 20]
     else:
         p0, pf, space = generate_grid_swap(n, seed=seed, dim=dim)
-    s, traj = solve_gpu(n, 10.0, 0.2, 0.8, space, p0, pf, max_iterations=4, dim=dim, qp_settings={"max_iter": 2000})
+    s, traj = solve_gpu(n, 10.0, 0.2, 0.8, space, p0, pf, max_iterations=4, dim=dim,
+                        qp_settings={"max_iter": 2000, "cg_iters": cg})
     prob = so.make_problem(n, 10.0, 0.2, 0.8, space, p0, pf)
-    out = qo.scp_solve(prob, 4, qo.Settings(max_iter=2000))
+    out = qo.scp_solve(prob, 4, qo.Settings(max_iter=2000, cg_iters=cg))
     assert s.last_info["n_iterations"] == out["iterations"]
     for a, b in zip(s.last_info["iterations"], out["infos"][1:]):
         assert a["status_val"] == b["status_val"] and a["rounds"] == b["rounds"], (a, b)
-        assert abs(a["iter"] - b["iter"]) <= 50 and abs(a["working_rows"] - b["working_rows"]) <= 2, (a, b)
-    # eps_abs + eps_rel * max|Ax| = 1e-3 * (1 + ~20 m): the primal residual either solver may stop at
-    np.testing.assert_allclose(traj["positions"], out["positions"], rtol=0, atol=2e-2)
+        if cg > 1:
+            assert a["iter"] == b["iter"] and a["working_rows"] == b["working_rows"], (a, b)
+        else:
+            assert abs(a["iter"] - b["iter"]) <= 50 and abs(a["working_rows"] - b["working_rows"]) <= 2, (a, b)
+    # cg = 1: eps_abs + eps_rel * max|Ax| = 1e-3 * (1 + ~20 m), the primal residual either solver may stop at
+    np.testing.assert_allclose(traj["positions"], out["positions"], rtol=0, atol=2e-2 if cg == 1 else 1e-6)
     np.testing.assert_allclose([i["rel_step"] for i in s.last_info["iterations"]], out["rel_steps"], rtol=0.05, atol=2e-3)
     check_solution_properties(s, traj)

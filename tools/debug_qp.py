@@ -1,0 +1,37 @@
+"""Developer tool: one collision QP, GPU vs numpy oracle at increasing iteration caps (same inputs)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "ba-path-planning_amd"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import qp_oracle as qo, scp_oracle as so  # noqa: E402
+from path_planning import _hip  # noqa: E402
+from path_planning.scenarios.position_generator import generate_positions  # noqa: E402
+
+n, seed = int(sys.argv[1]), int(sys.argv[2])
+cg = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+p0, pf = generate_positions(n, 0.8, seed=seed)
+prob = so.make_problem(n, 10.0, 0.2, 0.8, [0, 0, 20, 20], p0, pf)
+x0, _, _ = qo.admm_structured(prob, st=qo.Settings(max_iter=2000))
+pos, _ = so.kinematics(prob, x0)
+eta, l, dist = so.linearize_pairs(prob, pos)
+W = np.nonzero(dist - prob.R < 0.5)[0]
+ctx = _hip.Context(0)
+for cap in (5, 25, 50, 100, 300):
+    st = qo.Settings(max_iter=cap, max_rounds=1, check_termination=10 ** 6, adaptive_rho=False, cg_iters=cg)
+    xo, yo, io = qo.admm_structured(prob, eta, l, dist, x0=x0, st=st, rows0=W)
+    hs = _hip.default_settings(max_iter=cap, check_termination=10 ** 6, adaptive_rho=0, cg_iters=cg)
+    qp = _hip.QP(ctx, prob.N, prob.K, 2, prob.h, hs)
+    qp.set_problem([-2, 2, -15, 15, -20, 20], [0, 0, 20, 20], ctx.tensor(prob.p0), ctx.tensor(prob.v0), ctx.tensor(prob.pf),
+                   ctx.tensor(prob.vf))
+    qp.reset(ctx.tensor(x0))
+    qp.add_rows(torch.as_tensor(W, dtype=torch.int64, device=ctx.tdev), ctx.tensor(eta[W]), ctx.tensor(l[W]))
+    info = qp.solve()
+    x = qp.solution().cpu().numpy()
+    _, yc = qp.duals()
+    print(f"cap {cap:4d}: |x-xo| {np.abs(x-xo).max():.3e}  |yc-yo| {np.abs(yc.cpu().numpy()-yo['col']).max():.3e}  |x| {np.abs(xo).max():.2f}")
+    qp.close()

@@ -873,6 +873,9 @@ static int check_pair_range(scp_ctx* ctx, int N, int K, int D, int64_t q_begin, 
               "pair pass: bad pair range [%lld, %lld) of %lld", (long long)q_begin, (long long)q_end,
               (long long)scp_pairs(N));
   SCP_REQUIRE(ctx, K <= 65535, "pair pass: K=%d exceeds grid.y", K);
+  SCP_REQUIRE(ctx, q_end - q_begin < ((int64_t)1 << 31) - 2 * PAIR_ROWS,
+              "pair pass: %lld pairs per call exceed the 32-bit lane offsets; shard the pair range",
+              (long long)(q_end - q_begin));
   return SCP_OK;
 }
 

@@ -305,3 +305,52 @@ def test_scp_sweep_vs_oracle(kind, n, seed, cg):
     np.testing.assert_allclose(traj["positions"], out["positions"], rtol=0, atol=2e-2 if cg == 1 else 1e-6)
     np.testing.assert_allclose([i["rel_step"] for i in s.last_info["iterations"]], out["rel_steps"], rtol=0.05, atol=2e-3)
     check_solution_properties(s, traj)
+
+
+def test_full_size_properties_1024x50():
+    """BASELINE config 3 at full size (1024 agents x 50 steps, 26.2 M collision rows): the oracle cannot finish a
+    solve here in test time, so the check is through size-independent properties."""
+    import torch
+
+    from path_planning.scenarios.position_generator import generate_grid_swap
+
+    N, K = 1024, 50
+    p0, pf, space = generate_grid_swap(N, seed=1000 * N)
+    s, traj = solve_gpu(N, K * 0.2 + 1e-9, 0.2, 0.8, space, p0, pf, max_iterations=15)
+    assert s.K == K and s.last_info["converged"] and 1 <= s.last_info["n_iterations"] <= 15
+    for it in s.last_info["iterations"]:
+        assert it["status_val"] == 1
+    check_solution_properties(s, traj)  # bitwise kinematics + every fixed row within the ADMM tolerance
+    rep = s.validate_solution()
+    assert rep["collision_free"] and rep["min_pair_distance"] >= 0.8 - 0.01
+    # the compact rows of the LAST linearisation, spot-checked against the oracle formulas on 20 000 random rows
+    prob = so.make_problem(N, K * 0.2 + 1e-9, 0.2, 0.8, space, p0, pf)
+    ctx, pp = s._ctx, s._pairs
+    acc = ctx.tensor(traj["accelerations"])
+    pos = ctx.tensor(traj["positions"])
+    p0d, v0d = ctx.tensor(prob.p0), ctx.tensor(prob.v0)
+    rows, min_dist, first = pp.linearize(pos, p0d, v0d, s.working_set_margin)
+    assert first == (1 << 64) - 1 and abs(min_dist - rep["min_pair_distance"]) < 1e-12
+    rng = np.random.default_rng(0)
+    sample = np.sort(rng.choice(prob.m_col, 20000, replace=False))
+    st = torch.as_tensor(sample, dtype=torch.int64, device=ctx.tdev)
+    w_eta, w_l = pp.gather(st)
+    iu, ju = so.pair_index(N)
+    k, q = sample // prob.pairs, sample % prob.pairs
+    P = traj["positions"]
+    diff = P[iu[q], k] - P[ju[q], k]
+    dist = np.hypot(diff[:, 0], diff[:, 1])
+    eta = diff / dist[:, None]
+    c = so.free_positions(prob)
+    l_ref = prob.R + (np.sum(eta * diff, axis=1) - dist) - np.sum(eta * (c[iu[q], k] - c[ju[q], k]), axis=1)
+    np.testing.assert_allclose(w_eta.cpu().numpy(), eta, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(w_l.cpu().numpy(), l_ref, rtol=0, atol=1e-12)
+    # selection == {rows with dist - R < margin} on the sample; and the pass is idempotent
+    sel = set(rows.cpu().numpy().tolist())
+    want = sample[dist - prob.R < s.working_set_margin]
+    assert all(int(r) in sel for r in want) and all(int(r) not in sel for r in sample[dist - prob.R >= s.working_set_margin])
+    rows2, _, _ = pp.linearize(pos, p0d, v0d, s.working_set_margin)
+    assert torch.equal(rows, rows2)
+    # at the returned solution no linearised row (around that same solution) is violated beyond the tolerance
+    new_rows, max_v = pp.violations(pos, p0d, v0d, 1e-6)
+    assert max_v <= 0.8 - rep["min_pair_distance"] + 1e-9  # l - A x = R - dist at the linearisation point itself

@@ -709,10 +709,11 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
   qp->row_cap = row_capacity;
   qp->nW = 0;
   qp->problem_set = qp->reset_done = false;
-  qp->cg1_ready = qp->csr_valid = false;
+  qp->cg1_ready = qp->csr_valid = qp->qx_fresh = false;
   qp->rho = s->rho;
   carve(qp->d, workspace, K, qp->C, row_capacity, D);
-  if (hipHostMalloc(&qp->h_scal, SL_COUNT * sizeof(double)) != hipSuccess) {
+  if (hipHostMalloc(&qp->h_scal, SL_COUNT * sizeof(double)) != hipSuccess ||
+      hipHostMalloc(&qp->h_part, SCP_PART_CAP * sizeof(double)) != hipSuccess) {
     delete qp;
     return scp_fail(ctx, SCP_ERR_HIP, "qp_create: hipHostMalloc failed");
   }
@@ -747,6 +748,7 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
             hipStreamSynchronize(st) == hipSuccess;
   if (!ok) {
     (void)hipHostFree(qp->h_scal);
+    (void)hipHostFree(qp->h_part);
     delete qp;
     return scp_fail(ctx, SCP_ERR_HIP, "qp_create: constant upload failed");
   }
@@ -758,6 +760,7 @@ extern "C" void scp_qp_destroy(scp_qp* qp) {
   if (!qp) return;
   (void)hipStreamSynchronize(qp->ctx->stream);
   (void)hipHostFree(qp->h_scal);
+  (void)hipHostFree(qp->h_part);
   delete qp;
 }
 
@@ -849,8 +852,11 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
     else if (fused) QP_CHECK(scp_qp_fused_iteration(qp, &cg_total));
     else QP_CHECK(admm_iteration(qp, &cg_total));
     if (will_check) {
-      QP_CHECK(residuals(qp, with_dy));
-      qp->cg1_ready = false;  // residuals() used G and the Q slabs as scratch; rho may change below
+      const bool cg1 = fused && st.cg_iters == 1 && qp->nW > 0 && qp->csr_valid &&
+                       (qp->C + 15) / 16 + 128 <= SCP_PART_CAP;
+      if (cg1) QP_CHECK(scp_qp_fused_residuals(qp, with_dy));
+      else QP_CHECK(residuals(qp, with_dy));
+      qp->cg1_ready = false;  // the check used gval / G and the Q slabs as scratch; rho may change below
       const double* hs = qp->h_scal;
       rp = hs[SL_RP];
       rd = hs[SL_RD];

@@ -729,7 +729,9 @@ int scp_qp_cg1_prepare(scp_qp* qp) {
   const int64_t C = qp->C, nx = (int64_t)K * C;
   double* Qx = d.HQ + nx;
   const double rho_c = qp->rho * qp->st.rho_col_scale;
-  int rc = scp_launch_gemm(qp->ctx, 1, K, K, (int)C, 1.0, d.S0, d.x, 0.0, Qx);
+  int rc = SCP_OK;
+  if (!qp->qx_fresh) rc = scp_launch_gemm(qp->ctx, 1, K, K, (int)C, 1.0, d.S0, d.x, 0.0, Qx);
+  qp->qx_fresh = false;
   if (rc) return rc;
   if (!qp->csr_valid) {
     rc = scp_qp_csr_build(qp);
@@ -937,5 +939,202 @@ int scp_qp_csr_scatter(scp_qp* qp, int mode, const double* vec) {
   hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, s, qp->K, qp->N, qp->D,
                      d.cell_ptr, d.coef, d.gval, d.G);
   FUSED_LAUNCHED(qp);
+  return SCP_OK;
+}
+
+// =====================================================================================================
+// Termination check of the single-step pipeline, fused: one row launch (gval = yc), one column-block launch
+// (F x, S0 x, A^T y = F^T y_f + S0^T gather, delta-y of the fixed rows, all their maxima), one row launch
+// (collision rows' residuals and delta-y).  14 launches on the generic path.
+// =====================================================================================================
+namespace {
+
+__device__ inline double wg_max(double v) {
+  __shared__ double s[NWV];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) t = fmax(t, s[w]);
+  __syncthreads();
+  return t;
+}
+
+__device__ inline void atomic_max_nn(double* addr, double v) {
+  atomicMax((unsigned long long*)addr, (unsigned long long)__double_as_longlong(v));
+}
+
+__global__ __launch_bounds__(FT) void cg1_resid_col_kernel(int K, int Rf, int64_t C, int N, int D, int with_dy,
+                                                            const double* __restrict__ F, const double* __restrict__ S0,
+                                                            const double* __restrict__ Ft, const double* __restrict__ S0t,
+                                                            const double* __restrict__ x, const double* __restrict__ zf,
+                                                            const double* __restrict__ yf, const double* __restrict__ lf,
+                                                            const double* __restrict__ uf, double* __restrict__ dyf,
+                                                            const int* __restrict__ cell_ptr,
+                                                            const double* __restrict__ coef,
+                                                            const double* __restrict__ gval, double* __restrict__ Qx,
+                                                            double* __restrict__ scal, double* __restrict__ part_supp) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* X = lds;               // [K][16]
+  double* T = X + K * CB;        // [Rf][16]  F x, then y_f
+  double* Q = T + Rf * CB;       // [K][16]   S0 x
+  double* Gt = Q + K * CB;       // [K][16]   gather of eta * yc
+  double* A1 = Gt + K * CB;      // [K][16]   F^T y (first half of the rows)
+  double* A1b = A1 + K * CB;     // [K][16]   F^T y (second half)
+  double* A2 = A1b + K * CB;     // [K][16]   S0^T G
+  const int64_t c0 = (int64_t)blockIdx.x * CB;
+  tile_load(X, x, K, C, c0);
+  for (int e = threadIdx.x; e < K * CB; e += FT) {
+    const int k = e >> 4, c = e & 15;
+    double acc = 0.0;
+    if (c0 + c < C) {
+      const int col = (int)(c0 + c);
+      const int agent = col / D, d = col - agent * D;
+      const int cell = k * N + agent;
+      const int t1 = cell_ptr[cell + 1];
+      for (int t = cell_ptr[cell]; t < t1; ++t) acc += coef[(size_t)t * D + d] * gval[t];
+    }
+    Gt[e] = acc;
+  }
+  __syncthreads();
+  wg_mm<false>(F, Rf, K, X, T, 0, NWV - 3);
+  wg_mm<false>(S0, K, K, X, Q, NWV - 3, 3);
+  __syncthreads();
+  double rp = 0.0, nax = 0.0, nz = 0.0, ndy = 0.0, supp = 0.0;
+  for (int e = threadIdx.x; e < Rf * CB; e += FT) {
+    const int r = e >> 4, c = e & 15;
+    double y = 0.0;
+    if (c0 + c < C) {
+      const int64_t g = (int64_t)r * C + c0 + c;
+      const double a = T[e], z = zf[g];
+      y = yf[g];
+      rp = fmax(rp, fabs(a - z));
+      nax = fmax(nax, fabs(a));
+      nz = fmax(nz, fabs(z));
+      if (with_dy) {
+        const double dd = y - dyf[g];
+        dyf[g] = dd;
+        ndy = fmax(ndy, fabs(dd));
+        supp += uf[g] * fmax(dd, 0.0) + lf[g] * fmin(dd, 0.0);
+      }
+    }
+    T[e] = y;  // same thread read T[e]: the tile now holds y_f
+  }
+  for (int e = threadIdx.x; e < K * CB; e += FT) {
+    const int r = e >> 4, c = e & 15;
+    if (c0 + c < C) Qx[(int64_t)r * C + c0 + c] = Q[e];
+  }
+  __syncthreads();
+  const int half = ((Rf / 2) + 3) & ~3;
+  wg_mm_range<false>(Ft, K, Rf, 0, half, T, A1, 0, 6);
+  wg_mm_range<false>(Ft, K, Rf, half, Rf, T, A1b, 6, 6);
+  wg_mm<false>(S0t, K, K, Gt, A2, 12, NWV - 12);
+  __syncthreads();
+  double rd = 0.0, npx = 0.0, nat = 0.0;
+  for (int e = threadIdx.x; e < K * CB; e += FT) {
+    const int c = e & 15;
+    if (c0 + c < C) {
+      const double aty = (A1[e] + A1b[e]) + A2[e], px = 2.0 * X[e];
+      rd = fmax(rd, fabs(px + aty));
+      npx = fmax(npx, fabs(px));
+      nat = fmax(nat, fabs(aty));
+    }
+  }
+  rp = wg_max(rp); nax = wg_max(nax); nz = wg_max(nz);
+  rd = wg_max(rd); npx = wg_max(npx); nat = wg_max(nat);
+  ndy = wg_max(ndy);
+  supp = wg_sum(supp);
+  if (threadIdx.x == 0) {
+    atomic_max_nn(scal + SL_RP, rp); atomic_max_nn(scal + SL_NAX, nax); atomic_max_nn(scal + SL_NZ, nz);
+    atomic_max_nn(scal + SL_RD, rd); atomic_max_nn(scal + SL_NPX, npx); atomic_max_nn(scal + SL_NATY, nat);
+    atomic_max_nn(scal + SL_NDY, ndy);
+    part_supp[blockIdx.x] = supp;  // summed on the host in block order: deterministic
+  }
+}
+
+constexpr int RESID_ROW_BLOCKS = 128;
+
+template <int D>
+__global__ __launch_bounds__(256) void cg1_resid_rows_kernel(int64_t nW, int64_t C, int with_dy, const int* __restrict__ wk,
+                                                              const int* __restrict__ wi, const int* __restrict__ wj,
+                                                              const double* __restrict__ weta,
+                                                              const double* __restrict__ wl, const double* __restrict__ Qx,
+                                                              const double* __restrict__ zc, const double* __restrict__ yc,
+                                                              double* __restrict__ dyc, double* __restrict__ scal,
+                                                              double* __restrict__ part_supp) {
+  __shared__ double sm[4][5];
+  double rp = 0.0, nax = 0.0, nz = 0.0, ndy = 0.0, supp = 0.0;
+  for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nW; n += (int64_t)RESID_ROW_BLOCKS * 256) {
+    const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
+    const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
+    double a = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) a += weta[n * D + d] * (Qx[bi + d] - Qx[bj + d]);
+    const double z = zc[n];
+    rp = fmax(rp, fabs(a - z));
+    nax = fmax(nax, fabs(a));
+    nz = fmax(nz, fabs(z));
+    if (with_dy) {
+      const double dd = fmin(yc[n] - dyc[n], 0.0);  // u = +inf: projected onto the polar of the recession cone
+      dyc[n] = dd;
+      ndy = fmax(ndy, fabs(dd));
+      supp += wl[n] * dd;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    rp = fmax(rp, __shfl_xor(rp, o)); nax = fmax(nax, __shfl_xor(nax, o)); nz = fmax(nz, __shfl_xor(nz, o));
+    ndy = fmax(ndy, __shfl_xor(ndy, o)); supp += __shfl_xor(supp, o);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[w][0] = rp; sm[w][1] = nax; sm[w][2] = nz; sm[w][3] = ndy; sm[w][4] = supp; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomic_max_nn(scal + SL_RP, fmax(fmax(sm[0][0], sm[1][0]), fmax(sm[2][0], sm[3][0])));
+    atomic_max_nn(scal + SL_NAX, fmax(fmax(sm[0][1], sm[1][1]), fmax(sm[2][1], sm[3][1])));
+    atomic_max_nn(scal + SL_NZ, fmax(fmax(sm[0][2], sm[1][2]), fmax(sm[2][2], sm[3][2])));
+    atomic_max_nn(scal + SL_NDY, fmax(fmax(sm[0][3], sm[1][3]), fmax(sm[2][3], sm[3][3])));
+    part_supp[blockIdx.x] = (sm[0][4] + sm[1][4]) + (sm[2][4] + sm[3][4]);
+  }
+}
+
+}  // namespace
+
+int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
+  const QpDev& d = qp->d;
+  scp_ctx* ctx = qp->ctx;
+  hipStream_t s = ctx->stream;
+  const int K = qp->K, Rf = qp->Rf;
+  const int64_t C = qp->C, nx = (int64_t)K * C;
+  const int nblk = (int)((C + CB - 1) / CB);
+  const size_t tile = (size_t)CB * sizeof(double);
+  double* Qx = d.HQ + nx;
+  double* part = d.part;  // [0, nblk): column blocks, [nblk, nblk + RESID_ROW_BLOCKS): row blocks
+  SCP_HIP_CHECK(ctx, hipMemsetAsync(d.scal + SL_RP, 0, 9 * sizeof(double), s));
+  hipLaunchKernelGGL(csr_rowval_kernel, dim3((unsigned)((qp->nW + 255) / 256)), dim3(256), 0, s, qp->nW, 1, 0.0, d.zc,
+                     d.yc, (const double*)nullptr, d.pos_i, d.pos_j, d.gval);
+  const size_t lds = (size_t)(Rf + 6 * K) * tile;
+  int rc = allow_lds(qp, cg1_resid_col_kernel, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(cg1_resid_col_kernel, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->N, qp->D, with_dy ? 1 : 0, d.F,
+                     d.S0, d.Ft, d.S0t, d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval, Qx, d.scal, part);
+  if (qp->D == 2)
+    hipLaunchKernelGGL(cg1_resid_rows_kernel<2>, dim3(RESID_ROW_BLOCKS), dim3(256), 0, s, qp->nW, C, with_dy ? 1 : 0, d.w_k,
+                       d.w_i, d.w_j, d.w_eta, d.w_l, Qx, d.zc, d.yc, d.dyc, d.scal, part + nblk);
+  else
+    hipLaunchKernelGGL(cg1_resid_rows_kernel<3>, dim3(RESID_ROW_BLOCKS), dim3(256), 0, s, qp->nW, C, with_dy ? 1 : 0, d.w_k,
+                       d.w_i, d.w_j, d.w_eta, d.w_l, Qx, d.zc, d.yc, d.dyc, d.scal, part + nblk);
+  FUSED_LAUNCHED(qp);
+  SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->h_scal, d.scal, SL_COUNT * sizeof(double), hipMemcpyDeviceToHost, s));
+  SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->h_part, part, (size_t)(nblk + RESID_ROW_BLOCKS) * sizeof(double),
+                                    hipMemcpyDeviceToHost, s));
+  SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  double supp = 0.0;
+  if (with_dy)
+    for (int b = 0; b < nblk + RESID_ROW_BLOCKS; ++b) supp += qp->h_part[b];
+  qp->h_scal[SL_SUPP] = supp;
+  qp->qx_fresh = true;
   return SCP_OK;
 }

@@ -49,6 +49,8 @@ struct scp_qp {
   bool problem_set, reset_done;
   bool cg1_ready;  // carried state (Qx, gval) of the single-step pipeline matches (x, zc, yc, rho)
   bool csr_valid;  // incidence lists match the working set
+  bool qx_fresh;   // the Qx slab holds S0 x exactly (written by the fused residual kernel)
+  double* h_part;  // pinned, SCP_PART_CAP doubles: per-workgroup partial sums read back at a termination check
   double rho;
   QpDev d;
   double* h_scal;  // pinned
@@ -66,3 +68,6 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count);
 // 2: g = vec[n].  Two launches, no atomics.
 int scp_qp_csr_scatter(scp_qp* qp, int mode, const double* vec);
 int scp_qp_csr_build(scp_qp* qp);
+// Termination-check quantities of the single-step pipeline in 3 launches (row values, column blocks, rows):
+// fills qp->h_scal[SL_RP .. SL_SUPP] like residuals() in scp_qp.hip and leaves S0 x in the Qx slab.  Synchronises.
+int scp_qp_fused_residuals(scp_qp* qp, bool with_dy);

@@ -426,6 +426,13 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.aug = c.take<double>((size_t)2 * K * K);
   d.wrow = c.take<double>((size_t)Rf);
   d.MS = c.take<double>((size_t)2 * K * K);
+  d.pF = c.take<double>(scp_packed_count(Rf, K));
+  d.pFt = c.take<double>(scp_packed_count(K, Rf));
+  d.pS0 = c.take<double>(scp_packed_count(K, K));
+  d.pS0t = c.take<double>(scp_packed_count(K, K));
+  d.pHS = c.take<double>(scp_packed_count(2 * K, K));
+  d.pMinv = c.take<double>(scp_packed_count(K, K));
+  d.pMS = c.take<double>(scp_packed_count(2 * K, K));
   const size_t nf = (size_t)Rf * C, nx = (size_t)K * C;
   d.lf = c.take<double>(nf);
   d.uf = c.take<double>(nf);
@@ -526,7 +533,7 @@ int build_kkt(scp_qp* qp) {
   // MS = [Minv ; S0 Minv]: p and S0 p from one product in the single-step pipeline
   SCP_HIP_CHECK(qp->ctx, hipMemcpyAsync(d.MS, d.Minv, (size_t)K * K * sizeof(double), hipMemcpyDeviceToDevice, s));
   QP_CHECK(scp_launch_gemm(qp->ctx, 1, K, K, K, 1.0, d.S0, d.Minv, 0.0, d.MS + (size_t)K * K));
-  return SCP_OK;
+  return scp_qp_pack_operands(qp);
 }
 
 int admm_iteration(scp_qp* qp, int* cg_count) {

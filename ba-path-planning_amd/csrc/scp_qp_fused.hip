@@ -16,26 +16,37 @@ namespace {
 constexpr int CB = 16;         // columns per workgroup
 constexpr int FT = 1024;       // threads per workgroup (16 waves: one 16-row output tile per wave in most products)
 constexpr int NWV = FT / 64;
+
+// Developer build (make prof -> libscp_hip_prof.so): wall-clock stamps (100 MHz) of one workgroup's phases.
+#ifdef SCP_PHASE_PROFILE
+__device__ unsigned long long scp_phase_clk[64];
+#define PHASE_MARK(slot)                                                                      \
+  do {                                                                                        \
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) scp_phase_clk[slot] = wall_clock64(); \
+  } while (0)
+#else
+#define PHASE_MARK(slot) ((void)0)
+#endif
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-// O[R][16] = (ACC ? O : 0) + A[R][M] . V[M][16];  A: global, row-major, leading dimension M;  V, O: distinct LDS tiles.
-// The waves [w0, w0+nw) of the workgroup share the row tiles; other waves return at once, so two independent
-// products can run side by side on disjoint wave sets.  The A operands of the NEXT chunk of 16 k-steps are loaded
-// while the MFMAs of the current chunk issue (one L2 latency per product instead of one per chunk).
+// O[R][16] = (ACC ? O : 0) + A[R][M] . V[M][16];  A: global, PACKED in operand order (QpDev::pF ...: [row tile][k step]
+// [lane], zero padded);  V, O: distinct LDS tiles.  The waves [w0, w0+nw) of the workgroup share the row tiles; other
+// waves return at once, so independent products run side by side on disjoint wave sets.  One operand load is 512
+// contiguous bytes per wave (row-major A cost 16 cache lines per load and kept the L1 busy for most of a phase).  The
+// operands of the NEXT chunk of 16 k-steps are loaded while the MFMAs of the current chunk issue.
 // Operand maps of v_mfma_f64_16x16x4_f64 as in scp_gemm.hip.  Caller synchronises before reading O.
 template <bool ACC>
-__device__ inline void wg_mm_range(const double* __restrict__ A, int R, int M, int kb, int ke, const double* V, double* O,
+__device__ inline void wg_mm_range(const double* __restrict__ P, int R, int M, int kb, int ke, const double* V, double* O,
                                    int w0, int nw) {
-  // O[R][16] (+)= A[R][kb:ke] . V[kb:ke][16]   (A has leading dimension M, V is indexed by the absolute k)
+  // O[R][16] (+)= A[R][kb:ke] . V[kb:ke][16]   (kb a multiple of 4; V is indexed by the absolute k)
   const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) - w0;
   if (wave < 0 || wave >= nw) return;
   const int li = lane & 15, lk = lane >> 4;
-  const int tiles = (R + 15) >> 4;
+  const int tiles = (R + 15) >> 4, nks = (M + 3) >> 2;
+  const int ks0 = kb >> 2, ks1 = (ke + 3) >> 2;
   for (int t = wave; t < tiles; t += nw) {
     const int r0 = t * 16;
-    const int arow = r0 + li;
-    const bool rok = arow < R;
-    const double* Ap = A + (size_t)(rok ? arow : 0) * M;
+    const double* Ap = P + (size_t)t * nks * 64 + lane;
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
     if (ACC) {
 #pragma unroll
@@ -46,23 +57,17 @@ __device__ inline void wg_mm_range(const double* __restrict__ A, int R, int M, i
     }
     double a[16], an[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int kk = kb + 4 * s + lk;
-      a[s] = (rok && kk < ke) ? Ap[kk] : 0.0;
-    }
-    for (int kc = kb; kc < ke; kc += 64) {
-      const bool more = kc + 64 < ke;  // wave-uniform
+    for (int s = 0; s < 16; ++s) a[s] = Ap[(size_t)min(ks0 + s, ks1 - 1) * 64];  // clamped: straight-line loads
+    for (int kc = ks0; kc < ks1; kc += 16) {
+      const bool more = kc + 16 < ks1;  // wave-uniform
       if (more) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          const int kk = kc + 64 + 4 * s + lk;
-          an[s] = (rok && kk < ke) ? Ap[kk] : 0.0;
-        }
+        for (int s = 0; s < 16; ++s) an[s] = Ap[(size_t)min(kc + 16 + s, ks1 - 1) * 64];
       }
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        if (kc + 4 * s < ke) {  // wave-uniform
-          const int kk = kc + 4 * s + lk;
+        if (kc + s < ks1) {  // wave-uniform
+          const int kk = 4 * (kc + s) + lk;
           const double b = kk < ke ? V[kk * CB + li] : 0.0;
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b, acc, 0, 0, 0);
         }
@@ -468,6 +473,7 @@ __global__ __launch_bounds__(FT) void cg1_colA_kernel(int K, int Rf, int64_t C, 
   double* T2 = T1b + K * CB;        // [K][16]    H_f x
   double* T3 = T2 + K * CB;         // [K][16]    S0^T G
   const int64_t c0 = (int64_t)blockIdx.x * CB;
+  PHASE_MARK(0);
   tile_load(X, x, K, C, c0);
   // G = A_W^T g for this block's (time step, agent) cells, gathered from the incidence lists in a fixed order:
   // deterministic, no atomics, no G slab
@@ -489,20 +495,25 @@ __global__ __launch_bounds__(FT) void cg1_colA_kernel(int K, int Rf, int64_t C, 
     W[e] = (c0 + c < C) ? rho * wrow[r] * zf[g] - yf[g] : 0.0;
   }
   __syncthreads();
+  PHASE_MARK(1);
   const int half = ((Rf / 2) + 3) & ~3;
   wg_mm_range<false>(Ft, K, Rf, 0, half, W, T1, 0, 4);
   wg_mm_range<false>(Ft, K, Rf, half, Rf, W, T1b, 4, 4);
   wg_mm<false>(HS, K, K, X, T2, 8, 4);             // H_f x   (first K rows of [H_f; S0])
   wg_mm<false>(S0t, K, K, Gt, T3, 12, NWV - 12);
   __syncthreads();
+  PHASE_MARK(2);
   for (int e = threadIdx.x; e < K * CB; e += FT) T1[e] = ((T1[e] + T1b[e]) + sigma * X[e]) - T2[e] + T3[e];  // r
   __syncthreads();
+  PHASE_MARK(3);
   wg_mm<false>(MS, 2 * K, K, T1, W, 0, NWV);       // [p ; Qp]
   __syncthreads();
+  PHASE_MARK(4);
   double rz = 0.0;
   for (int e = threadIdx.x; e < K * CB; e += FT) rz += T1[e] * W[e];
   rz = wg_sum(rz);
   if (threadIdx.x == 0) part_rz[blockIdx.x] = rz;
+  PHASE_MARK(5);
   for (int e = threadIdx.x; e < K * CB; e += FT) {
     const int rr = e >> 4, c = e & 15;
     if (c0 + c < C) {
@@ -511,6 +522,7 @@ __global__ __launch_bounds__(FT) void cg1_colA_kernel(int K, int Rf, int64_t C, 
       Qp[g] = W[K * CB + e];
     }
   }
+  PHASE_MARK(6);
 }
 
 template <int D>
@@ -549,18 +561,29 @@ __global__ __launch_bounds__(FT) void cg1_post_kernel(int K, int Rf, int64_t C, 
   double* T = X + K * CB;           // [Rf][16]  F x~
   double* Q1 = T + Rf * CB;         // [K][16]   S0 x~
   const int64_t c0 = (int64_t)blockIdx.x * CB;
+  PHASE_MARK(16);
   const double rz = sum_parts(part_rz, nblk);
   const double pHp = rz + sum_parts(part_sq, SQ_BLOCKS);  // p.H_f p = p.r because p = H_f^{-1} r
   const double a = (pHp > 0.0 && rz != 0.0) ? rz / pHp : 0.0;
+  PHASE_MARK(17);
   for (int e = threadIdx.x; e < K * CB; e += FT) {
     const int r = e >> 4, c = e & 15;
     const int64_t g = (int64_t)r * C + c0 + c;
     X[e] = (c0 + c < C) ? x[g] + a * pdir[g] : 0.0;
   }
   __syncthreads();
+  PHASE_MARK(18);
   wg_mm<false>(F, Rf, K, X, T, 0, NWV - 3);
   wg_mm<false>(S0, K, K, X, Q1, NWV - 3, 3);
   __syncthreads();
+  PHASE_MARK(19);
+#ifdef SCP_PHASE_PROFILE
+  // warm repeat of the same products (idempotent): separates cold instruction / operand fetch from the MFMA work
+  wg_mm<false>(F, Rf, K, X, T, 0, NWV - 3);
+  wg_mm<false>(S0, K, K, X, Q1, NWV - 3, 3);
+  __syncthreads();
+  PHASE_MARK(24);
+#endif
   for (int e = threadIdx.x; e < Rf * CB; e += FT) {
     const int r = e >> 4, c = e & 15;
     if (c0 + c < C) {
@@ -573,6 +596,7 @@ __global__ __launch_bounds__(FT) void cg1_post_kernel(int K, int Rf, int64_t C, 
       zf[g] = zn;
     }
   }
+  PHASE_MARK(20);
   for (int e = threadIdx.x; e < K * CB; e += FT) {
     const int r = e >> 4, c = e & 15;
     if (c0 + c < C) {
@@ -582,6 +606,7 @@ __global__ __launch_bounds__(FT) void cg1_post_kernel(int K, int Rf, int64_t C, 
       Qx[g] = alpha * Q1[e] + (1.0 - alpha) * Qx[g];
     }
   }
+  PHASE_MARK(21);
 }
 
 // update = 1: z, y of the collision rows from Qt (= S0 x~); then the row values of the NEXT x-update's right-hand
@@ -658,7 +683,7 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
     if (rc) return rc;
   }
   hipLaunchKernelGGL(fused_pre_kernel, cgrid, cblock, (size_t)(4 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.sigma,
-                     has_rows, d.Ft, d.HS, d.Minv, d.wrow, d.x, d.zf, d.yf, d.rhs, Q, d.xt, d.G);
+                     has_rows, d.pFt, d.pHS, d.pMinv, d.wrow, d.x, d.zf, d.yf, d.rhs, Q, d.xt, d.G);
   FUSED_LAUNCHED(qp);
   if (has_rows) {
     if (qp->D == 2)
@@ -668,7 +693,7 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
       hipLaunchKernelGGL((fused_rows_kernel<3, true>), rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
                          d.w_eta, d.zc, d.yc, Q, d.G);
     FUSED_LAUNCHED(qp);
-    hipLaunchKernelGGL(fused_cg_init_kernel, cgrid, cblock, (size_t)(5 * K) * tile, s, K, C, d.S0t, d.Minv, d.HS, d.rhs,
+    hipLaunchKernelGGL(fused_cg_init_kernel, cgrid, cblock, (size_t)(5 * K) * tile, s, K, C, d.pS0t, d.pMinv, d.pHS, d.rhs,
                        d.G, d.r, d.p, d.hpf, Q, part_rz);
     FUSED_LAUNCHED(qp);
     int slot = SL_RZ0;
@@ -681,7 +706,7 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
         hipLaunchKernelGGL((fused_rows_kernel<3, false>), rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
                            d.w_eta, d.zc, d.yc, Q, d.G);
       FUSED_LAUNCHED(qp);
-      hipLaunchKernelGGL(fused_cg_hp_kernel, cgrid, cblock, (size_t)(2 * K) * tile, s, K, C, d.S0t, d.G, d.hpf, d.p, Hp,
+      hipLaunchKernelGGL(fused_cg_hp_kernel, cgrid, cblock, (size_t)(2 * K) * tile, s, K, C, d.pS0t, d.G, d.hpf, d.p, Hp,
                          part_php);
       FUSED_LAUNCHED(qp);
       ++*cg_count;
@@ -697,16 +722,16 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
       double* part_new = (it & 1) ? part_rz : part_rz + SCP_PART_CAP / 2;
       double* part_old = (it & 1) ? part_rz + SCP_PART_CAP / 2 : part_rz;
       hipLaunchKernelGGL(fused_cg_step_kernel, cgrid, cblock, (size_t)(2 * K) * tile, s, K, C, nblk, it == 0 ? 1 : 0, slot,
-                         d.Minv, d.scal, part_old, part_php, d.p, Hp, d.xt, d.r, d.zz, part_new);
+                         d.pMinv, d.scal, part_old, part_php, d.p, Hp, d.xt, d.r, d.zz, part_new);
       FUSED_LAUNCHED(qp);
-      hipLaunchKernelGGL(fused_cg_dir_kernel, cgrid, cblock, (size_t)(3 * K) * tile, s, K, C, nblk, slot, d.HS, d.scal,
+      hipLaunchKernelGGL(fused_cg_dir_kernel, cgrid, cblock, (size_t)(3 * K) * tile, s, K, C, nblk, slot, d.pHS, d.scal,
                          part_new, d.zz, d.p, d.hpf, Q);
       FUSED_LAUNCHED(qp);
       slot ^= 1;
     }
   }
   hipLaunchKernelGGL(fused_post_kernel, cgrid, cblock, (size_t)(2 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.alpha,
-                     has_rows, fold, nblk, fold_first, fold_slot, d.scal, fold_part, part_php, d.p, d.F, d.S0, d.wrow, d.xt,
+                     has_rows, fold, nblk, fold_first, fold_slot, d.scal, fold_part, part_php, d.p, d.pF, d.pS0, d.wrow, d.xt,
                      d.lf, d.uf, d.zf, d.yf, d.x, Q);
   FUSED_LAUNCHED(qp);
   if (has_rows) {
@@ -773,8 +798,8 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count) {
     if (!rc) rc = allow_lds(qp, cg1_post_kernel, (size_t)(2 * K + Rf) * tile);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(cg1_colA_kernel, cgrid, cblock, (size_t)(6 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.sigma, d.Ft,
-                     d.HS, d.S0t, d.MS, d.wrow, d.x, d.zf, d.yf, qp->N, qp->D, d.cell_ptr, d.coef, d.gval, d.p, Qp, part_rz);
+  hipLaunchKernelGGL(cg1_colA_kernel, cgrid, cblock, (size_t)(6 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.sigma, d.pFt,
+                     d.pHS, d.pS0t, d.pMS, d.wrow, d.x, d.zf, d.yf, qp->N, qp->D, d.cell_ptr, d.coef, d.gval, d.p, Qp, part_rz);
   FUSED_LAUNCHED(qp);
   if (qp->D == 2)
     hipLaunchKernelGGL(cg1_rows_sq_kernel<2>, dim3(SQ_BLOCKS), rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
@@ -784,7 +809,7 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count) {
                        d.w_eta, Qp, part_sq);
   FUSED_LAUNCHED(qp);
   hipLaunchKernelGGL(cg1_post_kernel, cgrid, cblock, (size_t)(2 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.alpha, nblk,
-                     part_rz, part_sq, d.p, d.F, d.S0, d.wrow, d.lf, d.uf, d.zf, d.yf, d.x, Qt, Qx);
+                     part_rz, part_sq, d.p, d.pF, d.pS0, d.wrow, d.lf, d.uf, d.zf, d.yf, d.x, Qt, Qx);
   FUSED_LAUNCHED(qp);
   if (qp->D == 2)
     hipLaunchKernelGGL(cg1_rows_ui_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, rho_c, qp->st.alpha, 1, d.w_k, d.w_i, d.w_j,
@@ -938,6 +963,48 @@ int scp_qp_csr_scatter(scp_qp* qp, int mode, const double* vec) {
                      qp->rho * qp->st.rho_col_scale, d.zc, d.yc, vec, d.pos_i, d.pos_j, d.gval);
   hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, s, qp->K, qp->N, qp->D,
                      d.cell_ptr, d.coef, d.gval, d.G);
+  FUSED_LAUNCHED(qp);
+  return SCP_OK;
+}
+
+// =====================================================================================================
+// Operand packing of the constant blocks (see QpDev::pF ...)
+// =====================================================================================================
+namespace {
+struct PackDesc {
+  const double* src;
+  double* dst;
+  int R, M;
+};
+struct PackArgs {
+  PackDesc m[7];
+};
+__global__ __launch_bounds__(256) void pack_operands_kernel(PackArgs a) {
+  const PackDesc d = a.m[blockIdx.y];
+  const int nks = (d.M + 3) >> 2;
+  const int64_t total = (int64_t)((d.R + 15) >> 4) * nks * 64;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int lane = (int)(e & 63);
+    const int64_t q = e >> 6;
+    const int ks = (int)(q % nks), t = (int)(q / nks);
+    const int row = t * 16 + (lane & 15), k = 4 * ks + (lane >> 4);
+    d.dst[e] = (row < d.R && k < d.M) ? d.src[(size_t)row * d.M + k] : 0.0;
+  }
+}
+}  // namespace
+
+int scp_qp_pack_operands(scp_qp* qp) {
+  const QpDev& d = qp->d;
+  const int K = qp->K, Rf = qp->Rf;
+  PackArgs a;
+  a.m[0] = {d.F, d.pF, Rf, K};
+  a.m[1] = {d.Ft, d.pFt, K, Rf};
+  a.m[2] = {d.S0, d.pS0, K, K};
+  a.m[3] = {d.S0t, d.pS0t, K, K};
+  a.m[4] = {d.HS, d.pHS, 2 * K, K};
+  a.m[5] = {d.Minv, d.pMinv, K, K};
+  a.m[6] = {d.MS, d.pMS, 2 * K, K};
+  hipLaunchKernelGGL(pack_operands_kernel, dim3(16, 7), dim3(256), 0, qp->ctx->stream, a);
   FUSED_LAUNCHED(qp);
   return SCP_OK;
 }
@@ -1118,8 +1185,8 @@ int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
   const size_t lds = (size_t)(Rf + 6 * K) * tile;
   int rc = allow_lds(qp, cg1_resid_col_kernel, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(cg1_resid_col_kernel, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->N, qp->D, with_dy ? 1 : 0, d.F,
-                     d.S0, d.Ft, d.S0t, d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval, Qx, d.scal, part);
+  hipLaunchKernelGGL(cg1_resid_col_kernel, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->N, qp->D, with_dy ? 1 : 0, d.pF,
+                     d.pS0, d.pFt, d.pS0t, d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval, Qx, d.scal, part);
   if (qp->D == 2)
     hipLaunchKernelGGL(cg1_resid_rows_kernel<2>, dim3(RESID_ROW_BLOCKS), dim3(256), 0, s, qp->nW, C, with_dy ? 1 : 0, d.w_k,
                        d.w_i, d.w_j, d.w_eta, d.w_l, Qx, d.zc, d.yc, d.dyc, d.scal, part + nblk);
@@ -1138,3 +1205,11 @@ int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
   qp->qx_fresh = true;
   return SCP_OK;
 }
+
+#ifdef SCP_PHASE_PROFILE
+// developer hook of the profiling build only (not declared in include/scp_hip.h)
+extern "C" int scp_debug_phase_clocks(unsigned long long* out, int n) {
+  if (n > 64) n = 64;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(scp_phase_clk), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -15,6 +15,10 @@ struct QpDev {
   // constant blocks
   double *F, *Ft, *S0, *S0t, *HS, *Hf, *Minv, *aug, *wrow;
   double* MS;  // [2K][K]: [H_f^{-1} ; S0 H_f^{-1}]
+  // the same blocks in MFMA A-operand order for the column-block kernels (scp_qp_pack_operands):
+  // [row tile][k step][lane] = A[16 tile + (lane & 15)][4 step + (lane >> 4)], zero beyond the matrix, so that one
+  // wave-wide operand load is 512 contiguous bytes
+  double *pF, *pFt, *pS0, *pS0t, *pHS, *pMinv, *pMS;
   // fixed rows
   double *lf, *uf, *zf, *yf, *wf, *tf;
   // x-space vectors [K][C]
@@ -68,6 +72,9 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count);
 // 2: g = vec[n].  Two launches, no atomics.
 int scp_qp_csr_scatter(scp_qp* qp, int mode, const double* vec);
 int scp_qp_csr_build(scp_qp* qp);
+// (re)pack F, Ft, S0, S0t, HS, Minv, MS into the MFMA operand order; called at the end of build_kkt
+int scp_qp_pack_operands(scp_qp* qp);
+static inline size_t scp_packed_count(int R, int M) { return (size_t)((R + 15) / 16) * ((M + 3) / 4) * 64; }
 // Termination-check quantities of the single-step pipeline in 3 launches (row values, column blocks, rows):
 // fills qp->h_scal[SL_RP .. SL_SUPP] like residuals() in scp_qp.hip and leaves S0 x in the Qx slab.  Synchronises.
 int scp_qp_fused_residuals(scp_qp* qp, bool with_dy);

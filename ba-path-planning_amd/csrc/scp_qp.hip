@@ -425,14 +425,14 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.Minv = c.take<double>((size_t)K * K);
   d.aug = c.take<double>((size_t)2 * K * K);
   d.wrow = c.take<double>((size_t)Rf);
-  d.MS = c.take<double>((size_t)2 * K * K);
+  d.MS = c.take<double>((size_t)(2 * K + Rf) * K);
   d.pF = c.take<double>(scp_packed_count(Rf, K));
   d.pFt = c.take<double>(scp_packed_count(K, Rf));
   d.pS0 = c.take<double>(scp_packed_count(K, K));
   d.pS0t = c.take<double>(scp_packed_count(K, K));
   d.pHS = c.take<double>(scp_packed_count(2 * K, K));
   d.pMinv = c.take<double>(scp_packed_count(K, K));
-  d.pMS = c.take<double>(scp_packed_count(2 * K, K));
+  d.pMS = c.take<double>(scp_packed_count(2 * K + Rf, K));
   const size_t nf = (size_t)Rf * C, nx = (size_t)K * C;
   d.lf = c.take<double>(nf);
   d.uf = c.take<double>(nf);
@@ -459,6 +459,7 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.scal = c.take<double>(SL_COUNT);
   d.part = c.take<double>(2 * SCP_PART_CAP);
   d.hpf = c.take<double>(nx);
+  d.fx = c.take<double>(nf);
   d.dyf = c.take<double>(nf);
   d.dyc = c.take<double>((size_t)cap);
   const size_t ncell = (size_t)(C / D) * K;
@@ -530,9 +531,10 @@ int build_kkt(scp_qp* qp) {
   QP_LAUNCHED(qp);
   hipLaunchKernelGGL(spd_inverse_kernel, dim3(1), dim3(1024), (size_t)3 * K * sizeof(double), s, K, d.aug, d.Minv);
   QP_LAUNCHED(qp);
-  // MS = [Minv ; S0 Minv]: p and S0 p from one product in the single-step pipeline
+  // MS = [Minv ; S0 Minv ; F Minv]: p, S0 p and F p from one product in the single-step pipeline
   SCP_HIP_CHECK(qp->ctx, hipMemcpyAsync(d.MS, d.Minv, (size_t)K * K * sizeof(double), hipMemcpyDeviceToDevice, s));
   QP_CHECK(scp_launch_gemm(qp->ctx, 1, K, K, K, 1.0, d.S0, d.Minv, 0.0, d.MS + (size_t)K * K));
+  QP_CHECK(scp_launch_gemm(qp->ctx, 1, qp->Rf, K, K, 1.0, d.F, d.Minv, 0.0, d.MS + (size_t)2 * K * K));
   return scp_qp_pack_operands(qp);
 }
 
@@ -717,6 +719,7 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
   qp->nW = 0;
   qp->problem_set = qp->reset_done = false;
   qp->cg1_ready = qp->csr_valid = qp->qx_fresh = false;
+  qp->qx_sel = 0;
   qp->rho = s->rho;
   carve(qp->d, workspace, K, qp->C, row_capacity, D);
   if (hipHostMalloc(&qp->h_scal, SL_COUNT * sizeof(double)) != hipSuccess ||
@@ -805,6 +808,7 @@ extern "C" int scp_qp_reset(scp_qp* qp, const double* x0) {
   qp->rho = qp->st.rho;
   qp->cg1_ready = false;
   qp->csr_valid = false;
+  qp->qx_fresh = false;
   QP_CHECK(build_kkt(qp));
   qp->reset_done = true;
   return SCP_OK;
@@ -828,6 +832,7 @@ extern "C" int scp_qp_add_rows(scp_qp* qp, int64_t n, const int64_t* rows, const
   qp->nW += n;
   qp->cg1_ready = false;
   qp->csr_valid = false;
+  qp->qx_fresh = false;  // HQ was scratch
   return SCP_OK;
 }
 
@@ -941,6 +946,7 @@ extern "C" int scp_qp_clone_state(scp_qp* dst, const scp_qp* src) {
   dst->problem_set = true;
   dst->cg1_ready = false;
   dst->csr_valid = false;
+  dst->qx_fresh = false;
   QP_CHECK(build_kkt(dst));
   dst->reset_done = true;
   SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // src's workspace may be released by the caller right after

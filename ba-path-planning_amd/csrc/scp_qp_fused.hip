@@ -451,78 +451,297 @@ __global__ __launch_bounds__(256) void fused_row_update_kernel(int64_t nW, int64
 //   rows_ui  : collision rows' z, y from Qt; then G += eta (rho zc - yc - rho eta.dQx+)   (next step's scatter)
 // =====================================================================================================
 constexpr int SQ_BLOCKS = 128;
+constexpr int CHB = 16;  // operand registers (k steps) held at once by a tile product
 
-__global__ __launch_bounds__(FT) void cg1_colA_kernel(int K, int Rf, int64_t C, double rho, double sigma,
-                                                       const double* __restrict__ Ft, const double* __restrict__ HS,
-                                                       const double* __restrict__ S0t, const double* __restrict__ MS,
-                                                       const double* __restrict__ wrow, const double* __restrict__ x,
-                                                       const double* __restrict__ zf, const double* __restrict__ yf,
-                                                       int N, int D, const int* __restrict__ cell_ptr,
-                                                       const double* __restrict__ coef,
-                                                       const double* __restrict__ gval, double* __restrict__ p,
-                                                       double* __restrict__ Qp, double* __restrict__ part_rz) {
-  // Two MFMA phases.  A: four independent products side by side on four wave groups -- F^T W split in two halves
-  // of its inner dimension, H_f x, S0^T G.  B: [p ; Qp] = [Minv ; S0 Minv] r  (H_f p = r needs no product, so
-  // p.H p = r.p + rho sum_rows (eta.dQp)^2 and the only inner product left is r.p).
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* X = lds;                  // [K][16]
-  double* W = X + K * CB;           // [Rf][16]   later: [p ; Qp] (2K <= Rf rows)
-  double* Gt = W + Rf * CB;         // [K][16]
-  double* T1 = Gt + K * CB;         // [K][16]    F^T W (first half), then r
-  double* T1b = T1 + K * CB;        // [K][16]    F^T W (second half)
-  double* T2 = T1b + K * CB;        // [K][16]    H_f x
-  double* T3 = T2 + K * CB;         // [K][16]    S0^T G
-  const int64_t c0 = (int64_t)blockIdx.x * CB;
-  PHASE_MARK(0);
-  tile_load(X, x, K, C, c0);
-  // G = A_W^T g for this block's (time step, agent) cells, gathered from the incidence lists in a fixed order:
-  // deterministic, no atomics, no G slab
-  for (int e = threadIdx.x; e < K * CB; e += FT) {
-    const int k = e >> 4, c = e & 15;
-    double acc = 0.0;
-    if (c0 + c < C) {
-      const int col = (int)(c0 + c);
-      const int agent = col / D, d = col - agent * D;
-      const int cell = k * N + agent;
-      const int t1 = cell_ptr[cell + 1];
-      for (int t = cell_ptr[cell]; t < t1; ++t) acc += coef[(size_t)t * D + d] * gval[t];
+// One 16-row tile of  O = A[:, 4 ks0 : ke] . V  with A packed (wg_mm_range); the first CH k-steps' operands can be
+// fetched long before V exists (tile_prefetch at kernel entry, tile_product after the barrier).
+template <int CH>
+__device__ inline void tile_prefetch(const double* __restrict__ P, int nks, int t, int ks0, int ks1, double (&a)[CH]) {
+  const double* Ap = P + (size_t)t * nks * 64 + (threadIdx.x & 63);
+#pragma unroll
+  for (int s = 0; s < CH; ++s) a[s] = Ap[(size_t)min(ks0 + s, ks1 - 1) * 64];
+}
+template <int CH>
+__device__ inline void tile_product(const double* __restrict__ P, int R, int nks, int t, int ks0, int ks1, int ke,
+                                    const double* V, double* O, double (&a)[CH]) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  const double* Ap = P + (size_t)t * nks * 64 + lane;
+  double4_t acc = {0.0, 0.0, 0.0, 0.0};
+  for (int kc = ks0; kc < ks1; kc += CH) {
+    if (kc > ks0) {  // beyond the prefetched chunk (K > 60 only)
+#pragma unroll
+      for (int s = 0; s < CH; ++s) a[s] = Ap[(size_t)min(kc + s, ks1 - 1) * 64];
     }
-    Gt[e] = acc;
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+      if (kc + s < ks1) {  // wave-uniform
+        const int kk = 4 * (kc + s) + lk;
+        const double b = kk < ke ? V[kk * CB + li] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b, acc, 0, 0, 0);
+      }
+    }
   }
-  for (int e = threadIdx.x; e < Rf * CB; e += FT) {
-    const int r = e >> 4, c = e & 15;
-    const int64_t g = (int64_t)r * C + c0 + c;
-    W[e] = (c0 + c < C) ? rho * wrow[r] * zf[g] - yf[g] : 0.0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = t * 16 + lk + 4 * r;
+    if (row < R) O[row * CB + li] = acc[r];
+  }
+}
+
+// ---- wave-wide prefix sums over the time index (one wave per column, lane l holds the E consecutive steps
+// k = l E + e): the integrator blocks V, S, S0 and their transposes are first and second cumulative sums ------------
+template <int E>
+__device__ inline void wave_scan_fwd(const double (&v)[E], double (&incl)[E], double (&excl)[E]) {
+  const int lane = threadIdx.x & 63;
+  double run = 0.0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    excl[e] = run;
+    run += v[e];
+    incl[e] = run;
+  }
+  double t = run;  // inclusive scan of the lane totals
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double y = __shfl_up(t, o);
+    if (lane >= o) t += y;
+  }
+  double off = __shfl_up(t, 1);  // total of the lower lanes
+  if (lane == 0) off = 0.0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    incl[e] += off;
+    excl[e] += off;
+  }
+}
+template <int E>
+__device__ inline void wave_scan_rev(const double (&v)[E], double (&incl)[E], double (&excl)[E]) {
+  const int lane = threadIdx.x & 63;
+  double run = 0.0;
+#pragma unroll
+  for (int e = E - 1; e >= 0; --e) {
+    excl[e] = run;
+    run += v[e];
+    incl[e] = run;
+  }
+  double t = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double y = __shfl_down(t, o);
+    if (lane + o < 64) t += y;
+  }
+  double off = __shfl_down(t, 1);  // total of the higher lanes
+  if (lane == 63) off = 0.0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    incl[e] += off;
+    excl[e] += off;
+  }
+}
+// value of the previous / next time step (0 outside)
+template <int E>
+__device__ inline void wave_prev(const double (&v)[E], double (&o)[E]) {
+  double y = __shfl_up(v[E - 1], 1);
+  if ((threadIdx.x & 63) == 0) y = 0.0;
+  o[0] = y;
+#pragma unroll
+  for (int e = 1; e < E; ++e) o[e] = v[e - 1];
+}
+template <int E>
+__device__ inline void wave_next(const double (&v)[E], double (&o)[E]) {
+  double y = __shfl_down(v[0], 1);
+  if ((threadIdx.x & 63) == 63) y = 0.0;
+  o[E - 1] = y;
+#pragma unroll
+  for (int e = 0; e + 1 < E; ++e) o[e] = v[e + 1];
+}
+
+// per-column LDS rows are padded to a length = 2 (mod 32) doubles: the (column, time) accesses of the coalesced
+// global <-> LDS copies (16 columns x 2 steps per half wave) and of the MFMA operand reads then hit 32 distinct banks
+__host__ __device__ inline int pad_col(int n) { return ((n + 29) / 32) * 32 + 2; }
+
+// Column kernel of the single-step pipeline (launch 1 of 3).  With F x carried like S0 x,
+//   r = sigma x + A^T(rho z - y) - H x = -2 x + F^T W' + S0^T G,   W' = rho w (z_f - F x) - y_f,
+// (H_f = (2 + sigma) I + rho F^T w F), then p = H_f^{-1} r, S0 p, F p.  F = [J ; I ; V ; S] and S0 are the jerk
+// stencil and the first / second cumulative sums of the integrator (scp.py:10-28, :489-491), so
+//   F^T W' + S0^T G = J^T w_j + w_a + rsum(h w_v + h^2/2 (w_p - g)) + h^2/2 g + h^2 rsum_excl(rsum(w_p + g))
+//   V p = h csum(p),  S p = h^2 (csum_excl(csum p) + csum(p)/2),  S0 p = h^2 (csum_excl(csum p) - csum(p)[k-1]/2)
+// cost one wave-wide scan each instead of a dense product: the only matrix left is H_f^{-1} (the KKT solve, MFMA).
+// Streaming the dense blocks (220 KB per workgroup for 16 columns) from L2 was 7 us of this kernel's 16.
+// One wave per column for the scans (E time steps per lane), waves [0, ceil(K/16)) for the MFMA tiles.
+template <int E>
+__global__ __launch_bounds__(FT) void cg1_col_kernel(int K, int Rf, int64_t C, double rho, double h,
+                                                      const double* __restrict__ pMinv, const double* __restrict__ wrow,
+                                                      const double* __restrict__ x, const double* __restrict__ Fx,
+                                                      const double* __restrict__ zf, const double* __restrict__ yf, int N,
+                                                      int D, const int* __restrict__ cell_ptr,
+                                                      const double* __restrict__ coef, const double* __restrict__ gval,
+                                                      double* __restrict__ p, double* __restrict__ Qp,
+                                                      double* __restrict__ Fp, double* __restrict__ part_rz) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ double s_rz[NWV];
+  const int RSF = pad_col(Rf), RSK = pad_col(K);
+  double* Wt = lds;              // [16][RSF]  W', later F p
+  double* Gx = Wt + CB * RSF;    // [16][RSK]  gather of eta * g
+  double* Xt = Gx + CB * RSK;    // [16][RSK]  x
+  double* Rt = Xt + CB * RSK;    // [16][RSK]  r
+  double* Pt = Rt + CB * RSK;    // [16][RSK]  p
+  double* Qt = Pt + CB * RSK;    // [16][RSK]  S0 p
+  const int64_t c0 = (int64_t)blockIdx.x * CB;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tK = (K + 15) >> 4, nks = (K + 3) >> 2;
+  const double hh = h * h;
+  PHASE_MARK(0);
+  // ---- prologue: every global load is issued before the first use --------------------------------------------
+  constexpr int WU = 4;  // slab rows per thread and pass: 64 WU >= Rf up to K = 64, a second pass beyond
+  const int c = threadIdx.x & 15, kg = threadIdx.x >> 4;
+  const bool cok = c0 + c < C;
+  const int col = (int)(c0 + c), agent = col / D, dd = col - agent * D;
+  double aM[CHB];
+  tile_prefetch<CHB>(pMinv, nks, wave < tK ? wave : 0, 0, nks, aM);
+  for (int k0 = 0; k0 < K; k0 += FT / CB) {
+    const int k = k0 + kg;
+    int g0 = 0, g1 = 0;
+    double xv = 0.0, acc = 0.0;
+    if (cok && k < K) {
+      g0 = cell_ptr[k * N + agent];
+      g1 = cell_ptr[k * N + agent + 1];
+      xv = x[(int64_t)k * C + c0 + c];
+    }
+    for (int t = g0; t < g1; ++t) acc += coef[(size_t)t * D + dd] * gval[t];
+    if (k < K) {
+      Gx[c * RSK + k] = acc;
+      Xt[c * RSK + k] = xv;
+    }
+  }
+  for (int r0 = 0; r0 < Rf; r0 += WU * (FT / CB)) {
+    double wz[WU], wf[WU], wy[WU];
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+      const int r = r0 + kg + u * (FT / CB);
+      wz[u] = wf[u] = wy[u] = 0.0;
+      if (cok && r < Rf) {
+        const int64_t g = (int64_t)r * C + c0 + c;
+        wz[u] = zf[g];
+        wf[u] = Fx[g];
+        wy[u] = yf[g];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+      const int r = r0 + kg + u * (FT / CB);
+      if (r < Rf) Wt[c * RSF + r] = rho * wrow[r] * (wz[u] - wf[u]) - wy[u];
+    }
   }
   __syncthreads();
   PHASE_MARK(1);
-  const int half = ((Rf / 2) + 3) & ~3;
-  wg_mm_range<false>(Ft, K, Rf, 0, half, W, T1, 0, 4);
-  wg_mm_range<false>(Ft, K, Rf, half, Rf, W, T1b, 4, 4);
-  wg_mm<false>(HS, K, K, X, T2, 8, 4);             // H_f x   (first K rows of [H_f; S0])
-  wg_mm<false>(S0t, K, K, Gt, T3, 12, NWV - 12);
-  __syncthreads();
-  PHASE_MARK(2);
-  for (int e = threadIdx.x; e < K * CB; e += FT) T1[e] = ((T1[e] + T1b[e]) + sigma * X[e]) - T2[e] + T3[e];  // r
-  __syncthreads();
-  PHASE_MARK(3);
-  wg_mm<false>(MS, 2 * K, K, T1, W, 0, NWV);       // [p ; Qp]
-  __syncthreads();
-  PHASE_MARK(4);
-  double rz = 0.0;
-  for (int e = threadIdx.x; e < K * CB; e += FT) rz += T1[e] * W[e];
-  rz = wg_sum(rz);
-  if (threadIdx.x == 0) part_rz[blockIdx.x] = rz;
-  PHASE_MARK(5);
-  for (int e = threadIdx.x; e < K * CB; e += FT) {
-    const int rr = e >> 4, c = e & 15;
-    if (c0 + c < C) {
-      const int64_t g = (int64_t)rr * C + c0 + c;
-      p[g] = W[e];
-      Qp[g] = W[K * CB + e];
+  // ---- r: one wave per column --------------------------------------------------------------------------------
+  double rr[E];
+  {
+    const double* Wc = Wt + wave * RSF;
+    double wj[E], wa[E], u1[E], u2[E], g[E], xk[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int k = lane * E + e;
+      const bool ok = k < K;
+      wj[e] = k < K - 1 ? Wc[k] : 0.0;
+      wa[e] = ok ? Wc[K - 1 + k] : 0.0;
+      const double wv = ok ? Wc[2 * K - 1 + k] : 0.0;
+      const double wp = ok ? Wc[3 * K - 1 + k] : 0.0;
+      g[e] = ok ? Gx[wave * RSK + k] : 0.0;
+      xk[e] = ok ? Xt[wave * RSK + k] : 0.0;
+      u1[e] = h * wv + 0.5 * hh * (wp - g[e]);
+      u2[e] = wp + g[e];
+    }
+    double d1[E], d2[E], s1[E], s2[E], wjp[E];
+    wave_scan_rev<E>(u1, d1, s1);   // d1 = rsum(u1)
+    wave_scan_rev<E>(u2, s1, s2);   // s1 = rsum(u2)
+    wave_scan_rev<E>(s1, s2, d2);   // d2 = rsum_excl(rsum(u2))
+    wave_prev<E>(wj, wjp);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int k = lane * E + e;
+      rr[e] = (((wjp[e] - wj[e]) / h + wa[e]) + (d1[e] + 0.5 * hh * g[e]) + hh * d2[e]) - 2.0 * xk[e];
+      if (k < K) Rt[wave * RSK + k] = rr[e];
     }
   }
-  PHASE_MARK(6);
+  __syncthreads();
+  PHASE_MARK(2);
+  // ---- p = H_f^{-1} r: one 16-row tile per wave -----------------------------------------------------------------
+  for (int t = wave; t < tK; t += NWV) {
+    const int li = lane & 15, lk = lane >> 4;
+    const double* Ap = pMinv + (size_t)t * nks * 64 + lane;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int kc = 0; kc < nks; kc += CHB) {
+      if (kc > 0 || t != wave) {
+#pragma unroll
+        for (int s = 0; s < CHB; ++s) aM[s] = Ap[(size_t)min(kc + s, nks - 1) * 64];
+      }
+#pragma unroll
+      for (int s = 0; s < CHB; ++s) {
+        if (kc + s < nks) {  // wave-uniform
+          const int kk = 4 * (kc + s) + lk;
+          const double b = kk < K ? Rt[li * RSK + kk] : 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aM[s], b, acc, 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = t * 16 + lk + 4 * r;
+      if (row < K) Pt[li * RSK + row] = acc[r];
+    }
+  }
+  __syncthreads();
+  PHASE_MARK(3);
+  // ---- S0 p, F p, r.p: one wave per column ------------------------------------------------------------------------
+  {
+    double* Wc = Wt + wave * RSF;
+    double pk[E], c1[E], c2[E], t1[E], t2[E], c1p[E], pn[E];
+    double rz = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int k = lane * E + e;
+      pk[e] = k < K ? Pt[wave * RSK + k] : 0.0;
+      rz += rr[e] * pk[e];
+    }
+    wave_scan_fwd<E>(pk, c1, t1);   // c1 = csum(p)
+    wave_scan_fwd<E>(c1, t2, c2);   // c2 = csum_excl(csum(p))
+    wave_prev<E>(c1, c1p);
+    wave_next<E>(pk, pn);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int k = lane * E + e;
+      if (k < K) {
+        Qt[wave * RSK + k] = hh * (c2[e] - 0.5 * c1p[e]);
+        if (k < K - 1) Wc[k] = (pn[e] - pk[e]) / h;
+        Wc[K - 1 + k] = pk[e];
+        Wc[2 * K - 1 + k] = h * c1[e];
+        Wc[3 * K - 1 + k] = hh * (c2[e] + 0.5 * c1[e]);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rz += __shfl_xor(rz, o);
+    if (lane == 0) s_rz[wave] = rz;
+  }
+  __syncthreads();
+  PHASE_MARK(4);
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) t += s_rz[w];
+    part_rz[blockIdx.x] = t;
+  }
+  // ---- coalesced stores ----------------------------------------------------------------------------------------------
+  if (cok) {
+    for (int k = kg; k < K; k += FT / CB) {
+      const int64_t g = (int64_t)k * C + c0 + c;
+      p[g] = Pt[c * RSK + k];
+      Qp[g] = Qt[c * RSK + k];
+    }
+    for (int r = kg; r < Rf; r += FT / CB) Fp[(int64_t)r * C + c0 + c] = Wt[c * RSF + r];
+  }
+  PHASE_MARK(5);
 }
 
 template <int D>
@@ -547,101 +766,122 @@ __global__ __launch_bounds__(256) void cg1_rows_sq_kernel(int64_t nW, int64_t C,
   if (threadIdx.x == 0) part_sq[blockIdx.x] = rho * ((sw[0] + sw[1]) + (sw[2] + sw[3]));
 }
 
-__global__ __launch_bounds__(FT) void cg1_post_kernel(int K, int Rf, int64_t C, double rho, double alpha, int nblk,
-                                                       const double* __restrict__ part_rz,
-                                                       const double* __restrict__ part_sq,
-                                                       const double* __restrict__ pdir, const double* __restrict__ F,
-                                                       const double* __restrict__ S0, const double* __restrict__ wrow,
-                                                       const double* __restrict__ lf, const double* __restrict__ uf,
-                                                       double* __restrict__ zf, double* __restrict__ yf,
-                                                       double* __restrict__ x, double* __restrict__ Qt,
-                                                       double* __restrict__ Qx) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* X = lds;                  // [K][16]   x~
-  double* T = X + K * CB;           // [Rf][16]  F x~
-  double* Q1 = T + Rf * CB;         // [K][16]   S0 x~
-  const int64_t c0 = (int64_t)blockIdx.x * CB;
-  PHASE_MARK(16);
-  const double rz = sum_parts(part_rz, nblk);
-  const double pHp = rz + sum_parts(part_sq, SQ_BLOCKS);  // p.H_f p = p.r because p = H_f^{-1} r
-  const double a = (pHp > 0.0 && rz != 0.0) ? rz / pHp : 0.0;
-  PHASE_MARK(17);
-  for (int e = threadIdx.x; e < K * CB; e += FT) {
-    const int r = e >> 4, c = e & 15;
-    const int64_t g = (int64_t)r * C + c0 + c;
-    X[e] = (c0 + c < C) ? x[g] + a * pdir[g] : 0.0;
+// step length a = r.p / p.H p  from the per-workgroup partials (p.H_f p = p.r because p = H_f^{-1} r); the same
+// instruction sequence in every 256-thread workgroup, so every workgroup holds the same bits
+__device__ inline double step_length_256(const double* __restrict__ part_rz, int nblk, const double* __restrict__ part_sq) {
+  __shared__ double sw[2][4];
+  double v = 0.0, q = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) v += part_rz[b];
+  for (int b = threadIdx.x; b < SQ_BLOCKS; b += 256) q += part_sq[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    v += __shfl_xor(v, o);
+    q += __shfl_xor(q, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sw[0][threadIdx.x >> 6] = v;
+    sw[1][threadIdx.x >> 6] = q;
   }
   __syncthreads();
-  PHASE_MARK(18);
-  wg_mm<false>(F, Rf, K, X, T, 0, NWV - 3);
-  wg_mm<false>(S0, K, K, X, Q1, NWV - 3, 3);
-  __syncthreads();
-  PHASE_MARK(19);
-#ifdef SCP_PHASE_PROFILE
-  // warm repeat of the same products (idempotent): separates cold instruction / operand fetch from the MFMA work
-  wg_mm<false>(F, Rf, K, X, T, 0, NWV - 3);
-  wg_mm<false>(S0, K, K, X, Q1, NWV - 3, 3);
-  __syncthreads();
-  PHASE_MARK(24);
-#endif
-  for (int e = threadIdx.x; e < Rf * CB; e += FT) {
-    const int r = e >> 4, c = e & 15;
-    if (c0 + c < C) {
-      const int64_t g = (int64_t)r * C + c0 + c;
-      const double rr = rho * wrow[r];
-      const double zh = alpha * T[e] + (1.0 - alpha) * zf[g];
-      const double y = yf[g];
-      const double zn = fmin(fmax(zh + y / rr, lf[g]), uf[g]);
-      yf[g] = y + rr * (zh - zn);
-      zf[g] = zn;
-    }
-  }
-  PHASE_MARK(20);
-  for (int e = threadIdx.x; e < K * CB; e += FT) {
-    const int r = e >> 4, c = e & 15;
-    if (c0 + c < C) {
-      const int64_t g = (int64_t)r * C + c0 + c;
-      x[g] = alpha * X[e] + (1.0 - alpha) * x[g];
-      Qt[g] = Q1[e];
-      Qx[g] = alpha * Q1[e] + (1.0 - alpha) * Qx[g];
-    }
-  }
-  PHASE_MARK(21);
+  const double rz = (sw[0][0] + sw[0][1]) + (sw[0][2] + sw[0][3]);
+  const double pHp = rz + ((sw[1][0] + sw[1][1]) + (sw[1][2] + sw[1][3]));
+  return (pHp > 0.0 && rz != 0.0) ? rz / pHp : 0.0;
 }
 
-// update = 1: z, y of the collision rows from Qt (= S0 x~); then the row values of the NEXT x-update's right-hand
-// side and H x:  g = rho zc - yc - rho eta.dQx  (A_W^T g is gathered by colA)
+constexpr int UPD_SEG = 16;  // row segments per 16-column block in the elementwise part of cg1_update_kernel
+
+// Launch 3 of 3: everything that follows the step length, elementwise.  Workgroups [0, eblocks): a sixteenth of
+// the slab rows of ONE 16-column block each -- fixed rows: F x~ = F x + a F p, z/y update, F x += alpha a F p; x rows:
+// x += alpha a p, S0 x (new buffer) = S0 x + alpha a S0 p.  Workgroup w works on column block w % nblk8 (nblk8 =
+// nblk rounded up to a multiple of 8): workgroups go round-robin over the 8 XCDs, so the slabs are rewritten in the L2
+// of the XCD whose cg1_col_kernel workgroup reads them next (a row-major split left every read a remote miss: 8 us
+// of load latency in the column kernel instead of 2.6).  Workgroups [eblocks, ...): collision rows -- S0 x~ and the
+// new S0 x formed on the fly from (S0 x, S0 p) with the same fma, z/y update, then the row values of the NEXT
+// right-hand side   g = rho zc - yc - rho eta.d(S0 x)      (A_W^T g is gathered by cg1_col_kernel).
 template <int D>
-__global__ __launch_bounds__(256) void cg1_rows_ui_kernel(int64_t nW, int64_t C, double rho, double alpha, int update,
-                                                           const int* __restrict__ wk, const int* __restrict__ wi,
-                                                           const int* __restrict__ wj, const double* __restrict__ weta,
-                                                           const double* __restrict__ wl, const double* __restrict__ Qt,
-                                                           const double* __restrict__ Qx, double* __restrict__ zc,
-                                                           double* __restrict__ yc, const int* __restrict__ pos_i,
-                                                           const int* __restrict__ pos_j, double* __restrict__ gval) {
+__global__ __launch_bounds__(256) void cg1_update_kernel(int K, int Rf, int64_t C, int nblk, int eblocks, int nblk8, double rho,
+                                                          double rho_c, double alpha, const double* __restrict__ part_rz,
+                                                          const double* __restrict__ part_sq,
+                                                          const double* __restrict__ wrow, const double* __restrict__ lf,
+                                                          const double* __restrict__ uf, double* __restrict__ zf,
+                                                          double* __restrict__ yf, double* __restrict__ Fx,
+                                                          const double* __restrict__ Fp, double* __restrict__ x,
+                                                          const double* __restrict__ pdir,
+                                                          const double* __restrict__ Qp, const double* __restrict__ Qx,
+                                                          double* __restrict__ Qn, int64_t nW, const int* __restrict__ wk,
+                                                          const int* __restrict__ wi, const int* __restrict__ wj,
+                                                          const double* __restrict__ weta, const double* __restrict__ wl,
+                                                          double* __restrict__ zc, double* __restrict__ yc,
+                                                          const int* __restrict__ pos_i, const int* __restrict__ pos_j,
+                                                          double* __restrict__ gval) {
+  const double a = step_length_256(part_rz, nblk, part_sq);
+  const double aa = alpha * a;
+  if ((int)blockIdx.x < eblocks) {
+    const int seg = blockIdx.x / nblk8, blk = blockIdx.x - seg * nblk8;
+    const int64_t col = (int64_t)blk * CB + (threadIdx.x & 15);
+    if (blk >= nblk || col >= C) return;
+    const int rows = Rf + K;
+    const int r1 = rows * (seg + 1) / UPD_SEG;
+    for (int row = rows * seg / UPD_SEG + (threadIdx.x >> 4); row < r1; row += 16) {
+      if (row < Rf) {
+        const double rr = rho * wrow[row];
+        const int64_t g = (int64_t)row * C + col;
+        const double fx = Fx[g], fp = Fp[g];
+        const double zh = alpha * fma(a, fp, fx) + (1.0 - alpha) * zf[g];
+        const double y = yf[g];
+        const double zn = fmin(fmax(zh + y / rr, lf[g]), uf[g]);
+        yf[g] = y + rr * (zh - zn);
+        zf[g] = zn;
+        Fx[g] = fma(aa, fp, fx);
+      } else {
+        const int64_t g = (int64_t)(row - Rf) * C + col;
+        x[g] = fma(aa, pdir[g], x[g]);
+        Qn[g] = fma(aa, Qp[g], Qx[g]);
+      }
+    }
+    return;
+  }
+  const int64_t n = (int64_t)(blockIdx.x - eblocks) * 256 + threadIdx.x;
+  if (n >= nW) return;
+  const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
+  const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
+  double tc = 0.0, ax = 0.0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const double e = weta[n * D + d];
+    const double qi = Qx[bi + d], qj = Qx[bj + d], pi = Qp[bi + d], pj = Qp[bj + d];
+    tc += e * (fma(a, pi, qi) - fma(a, pj, qj));
+    ax += e * (fma(aa, pi, qi) - fma(aa, pj, qj));
+  }
+  double z = zc[n], y = yc[n];
+  const double zh = alpha * tc + (1.0 - alpha) * z;
+  const double zn = fmax(zh + y / rho_c, wl[n]);
+  y = y + rho_c * (zh - zn);
+  z = zn;
+  yc[n] = y;
+  zc[n] = z;
+  const double g = (rho_c * z - y) - rho_c * ax;
+  gval[pos_i[n]] = g;
+  gval[pos_j[n]] = g;
+}
+
+// row values of the first right-hand side after (x, zc, yc, rho) changed outside the pipeline (S0 x exact in Qx)
+template <int D>
+__global__ __launch_bounds__(256) void cg1_rows_init_kernel(int64_t nW, int64_t C, double rho, const int* __restrict__ wk,
+                                                             const int* __restrict__ wi, const int* __restrict__ wj,
+                                                             const double* __restrict__ weta, const double* __restrict__ Qx,
+                                                             const double* __restrict__ zc, const double* __restrict__ yc,
+                                                             const int* __restrict__ pos_i, const int* __restrict__ pos_j,
+                                                             double* __restrict__ gval) {
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= nW) return;
   const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
   const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
-  double e[D], tc = 0.0, ax = 0.0;
+  double ax = 0.0;
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
-    e[d] = weta[n * D + d];
-    ax += e[d] * (Qx[bi + d] - Qx[bj + d]);
-  }
-  double z = zc[n], y = yc[n];
-  if (update) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) tc += e[d] * (Qt[bi + d] - Qt[bj + d]);
-    const double zh = alpha * tc + (1.0 - alpha) * z;
-    const double zn = fmax(zh + y / rho, wl[n]);
-    y = y + rho * (zh - zn);
-    z = zn;
-    yc[n] = y;
-    zc[n] = z;
-  }
-  const double g = (rho * z - y) - rho * ax;
-  gval[pos_i[n]] = g;  // the column kernels gather  sum coef * gval  per (time step, agent) cell
+  for (int d = 0; d < D; ++d) ax += weta[n * D + d] * (Qx[bi + d] - Qx[bj + d]);
+  const double g = (rho * zc[n] - yc[n]) - rho * ax;
+  gval[pos_i[n]] = g;
   gval[pos_j[n]] = g;
 }
 
@@ -746,46 +986,47 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
   return SCP_OK;
 }
 
-// Bring the single-step pipeline's carried state in line with (x, zc, yc, rho): Qx = S0 x exactly, G = scatter.
+// Bring the single-step pipeline's carried state in line with (x, zc, yc, rho): S0 x and F x exact, row values g.
 int scp_qp_cg1_prepare(scp_qp* qp) {
   const QpDev& d = qp->d;
   hipStream_t s = qp->ctx->stream;
   const int K = qp->K;
   const int64_t C = qp->C, nx = (int64_t)K * C;
-  double* Qx = d.HQ + nx;
   const double rho_c = qp->rho * qp->st.rho_col_scale;
-  int rc = SCP_OK;
-  if (!qp->qx_fresh) rc = scp_launch_gemm(qp->ctx, 1, K, K, (int)C, 1.0, d.S0, d.x, 0.0, Qx);
+  if (!qp->qx_fresh) {
+    qp->qx_sel = 0;
+    int rc = scp_launch_gemm(qp->ctx, 1, K, K, (int)C, 1.0, d.S0, d.x, 0.0, d.HQ + nx);
+    if (!rc) rc = scp_launch_gemm(qp->ctx, 1, qp->Rf, K, (int)C, 1.0, d.F, d.x, 0.0, d.fx);
+    if (rc) return rc;
+  }
   qp->qx_fresh = false;
-  if (rc) return rc;
+  const double* Qx = qp->qx_sel ? d.HQ : d.HQ + nx;
   if (!qp->csr_valid) {
-    rc = scp_qp_csr_build(qp);
+    int rc = scp_qp_csr_build(qp);
     if (rc) return rc;
   }
   const dim3 rgrid((unsigned)((qp->nW + 255) / 256)), rblock(256);
   if (qp->D == 2)
-    hipLaunchKernelGGL(cg1_rows_ui_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, rho_c, qp->st.alpha, 0, d.w_k, d.w_i,
-                       d.w_j, d.w_eta, d.w_l, d.HQ, Qx, d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
+    hipLaunchKernelGGL(cg1_rows_init_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j, d.w_eta, Qx,
+                       d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
   else
-    hipLaunchKernelGGL(cg1_rows_ui_kernel<3>, rgrid, rblock, 0, s, qp->nW, C, rho_c, qp->st.alpha, 0, d.w_k, d.w_i,
-                       d.w_j, d.w_eta, d.w_l, d.HQ, Qx, d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
+    hipLaunchKernelGGL(cg1_rows_init_kernel<3>, rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j, d.w_eta, Qx,
+                       d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
   FUSED_LAUNCHED(qp);
   qp->cg1_ready = true;
   return SCP_OK;
 }
 
+// One ADMM iteration with a single preconditioned CG step from x, in three launches: column blocks (r, then
+// [p ; S0 p ; F p]), collision rows (p.H p), elementwise update of every row and column (ping-pong of S0 x).
 int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count) {
   const QpDev& d = qp->d;
   hipStream_t s = qp->ctx->stream;
   const int K = qp->K, Rf = qp->Rf;
   const int64_t C = qp->C, nx = (int64_t)K * C;
   const int nblk = (int)((C + CB - 1) / CB);
-  const dim3 cgrid(nblk), cblock(FT);
-  const dim3 rgrid((unsigned)((qp->nW + 255) / 256)), rblock(256);
-  const size_t tile = (size_t)CB * sizeof(double);
-  double* Qx = d.HQ + nx;   // S0 x (carried)
-  double* Qt = d.HQ;        // S0 x~
-  double* Qp = d.hpf;       // S0 p
+  double* Qp = d.hpf;  // S0 p
+  double* Fp = d.tf;   // F p
   double* part_rz = d.part;
   double* part_sq = d.part + SCP_PART_CAP / 2;
   const double rho_c = qp->rho * qp->st.rho_col_scale;
@@ -793,14 +1034,22 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count) {
     int rc = scp_qp_cg1_prepare(qp);
     if (rc) return rc;
   }
-  {
-    int rc = allow_lds(qp, cg1_colA_kernel, (size_t)(6 * K + Rf) * tile);
-    if (!rc) rc = allow_lds(qp, cg1_post_kernel, (size_t)(2 * K + Rf) * tile);
+  double* Qx = qp->qx_sel ? d.HQ : d.HQ + nx;  // S0 x (carried)
+  double* Qn = qp->qx_sel ? d.HQ + nx : d.HQ;  // S0 x of the next iteration
+  const size_t lds = (size_t)CB * (pad_col(Rf) + 5 * pad_col(K)) * sizeof(double);
+  if (K <= 64) {
+    int rc = allow_lds(qp, cg1_col_kernel<1>, lds);
     if (rc) return rc;
+    hipLaunchKernelGGL(cg1_col_kernel<1>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->rho, qp->h, d.pMinv, d.wrow, d.x, d.fx,
+                       d.zf, d.yf, qp->N, qp->D, d.cell_ptr, d.coef, d.gval, d.p, Qp, Fp, part_rz);
+  } else {
+    int rc = allow_lds(qp, cg1_col_kernel<2>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cg1_col_kernel<2>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->rho, qp->h, d.pMinv, d.wrow, d.x, d.fx,
+                       d.zf, d.yf, qp->N, qp->D, d.cell_ptr, d.coef, d.gval, d.p, Qp, Fp, part_rz);
   }
-  hipLaunchKernelGGL(cg1_colA_kernel, cgrid, cblock, (size_t)(6 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.sigma, d.pFt,
-                     d.pHS, d.pS0t, d.pMS, d.wrow, d.x, d.zf, d.yf, qp->N, qp->D, d.cell_ptr, d.coef, d.gval, d.p, Qp, part_rz);
   FUSED_LAUNCHED(qp);
+  const dim3 rblock(256);
   if (qp->D == 2)
     hipLaunchKernelGGL(cg1_rows_sq_kernel<2>, dim3(SQ_BLOCKS), rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
                        d.w_eta, Qp, part_sq);
@@ -808,16 +1057,19 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count) {
     hipLaunchKernelGGL(cg1_rows_sq_kernel<3>, dim3(SQ_BLOCKS), rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
                        d.w_eta, Qp, part_sq);
   FUSED_LAUNCHED(qp);
-  hipLaunchKernelGGL(cg1_post_kernel, cgrid, cblock, (size_t)(2 * K + Rf) * tile, s, K, Rf, C, qp->rho, qp->st.alpha, nblk,
-                     part_rz, part_sq, d.p, d.pF, d.pS0, d.wrow, d.lf, d.uf, d.zf, d.yf, d.x, Qt, Qx);
-  FUSED_LAUNCHED(qp);
+  const int nblk8 = (nblk + 7) & ~7;
+  const int eblocks = nblk8 * UPD_SEG;
+  const dim3 ugrid((unsigned)(eblocks + (qp->nW + 255) / 256));
   if (qp->D == 2)
-    hipLaunchKernelGGL(cg1_rows_ui_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, rho_c, qp->st.alpha, 1, d.w_k, d.w_i, d.w_j,
-                       d.w_eta, d.w_l, Qt, Qx, d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
+    hipLaunchKernelGGL(cg1_update_kernel<2>, ugrid, rblock, 0, s, K, Rf, C, nblk, eblocks, nblk8, qp->rho, rho_c, qp->st.alpha,
+                       part_rz, part_sq, d.wrow, d.lf, d.uf, d.zf, d.yf, d.fx, Fp, d.x, d.p, Qp, Qx, Qn, qp->nW, d.w_k,
+                       d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
   else
-    hipLaunchKernelGGL(cg1_rows_ui_kernel<3>, rgrid, rblock, 0, s, qp->nW, C, rho_c, qp->st.alpha, 1, d.w_k, d.w_i, d.w_j,
-                       d.w_eta, d.w_l, Qt, Qx, d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
+    hipLaunchKernelGGL(cg1_update_kernel<3>, ugrid, rblock, 0, s, K, Rf, C, nblk, eblocks, nblk8, qp->rho, rho_c, qp->st.alpha,
+                       part_rz, part_sq, d.wrow, d.lf, d.uf, d.zf, d.yf, d.fx, Fp, d.x, d.p, Qp, Qx, Qn, qp->nW, d.w_k,
+                       d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
   FUSED_LAUNCHED(qp);
+  qp->qx_sel ^= 1;
   ++*cg_count;
   return SCP_OK;
 }
@@ -1003,7 +1255,7 @@ int scp_qp_pack_operands(scp_qp* qp) {
   a.m[3] = {d.S0t, d.pS0t, K, K};
   a.m[4] = {d.HS, d.pHS, 2 * K, K};
   a.m[5] = {d.Minv, d.pMinv, K, K};
-  a.m[6] = {d.MS, d.pMS, 2 * K, K};
+  a.m[6] = {d.MS, d.pMS, 2 * K + Rf, K};
   hipLaunchKernelGGL(pack_operands_kernel, dim3(16, 7), dim3(256), 0, qp->ctx->stream, a);
   FUSED_LAUNCHED(qp);
   return SCP_OK;
@@ -1042,7 +1294,8 @@ __global__ __launch_bounds__(FT) void cg1_resid_col_kernel(int K, int Rf, int64_
                                                             const int* __restrict__ cell_ptr,
                                                             const double* __restrict__ coef,
                                                             const double* __restrict__ gval, double* __restrict__ Qx,
-                                                            double* __restrict__ scal, double* __restrict__ part_supp) {
+                                                            double* __restrict__ Fx, double* __restrict__ scal,
+                                                            double* __restrict__ part_supp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* X = lds;               // [K][16]
   double* T = X + K * CB;        // [Rf][16]  F x, then y_f
@@ -1077,6 +1330,7 @@ __global__ __launch_bounds__(FT) void cg1_resid_col_kernel(int K, int Rf, int64_
       const int64_t g = (int64_t)r * C + c0 + c;
       const double a = T[e], z = zf[g];
       y = yf[g];
+      Fx[g] = a;
       rp = fmax(rp, fabs(a - z));
       nax = fmax(nax, fabs(a));
       nz = fmax(nz, fabs(z));
@@ -1177,7 +1431,7 @@ int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
   const int64_t C = qp->C, nx = (int64_t)K * C;
   const int nblk = (int)((C + CB - 1) / CB);
   const size_t tile = (size_t)CB * sizeof(double);
-  double* Qx = d.HQ + nx;
+  double* Qx = qp->qx_sel ? d.HQ : d.HQ + nx;
   double* part = d.part;  // [0, nblk): column blocks, [nblk, nblk + RESID_ROW_BLOCKS): row blocks
   SCP_HIP_CHECK(ctx, hipMemsetAsync(d.scal + SL_RP, 0, 9 * sizeof(double), s));
   hipLaunchKernelGGL(csr_rowval_kernel, dim3((unsigned)((qp->nW + 255) / 256)), dim3(256), 0, s, qp->nW, 1, 0.0, d.zc,
@@ -1186,7 +1440,7 @@ int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
   int rc = allow_lds(qp, cg1_resid_col_kernel, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(cg1_resid_col_kernel, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->N, qp->D, with_dy ? 1 : 0, d.pF,
-                     d.pS0, d.pFt, d.pS0t, d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval, Qx, d.scal, part);
+                     d.pS0, d.pFt, d.pS0t, d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval, Qx, d.fx, d.scal, part);
   if (qp->D == 2)
     hipLaunchKernelGGL(cg1_resid_rows_kernel<2>, dim3(RESID_ROW_BLOCKS), dim3(256), 0, s, qp->nW, C, with_dy ? 1 : 0, d.w_k,
                        d.w_i, d.w_j, d.w_eta, d.w_l, Qx, d.zc, d.yc, d.dyc, d.scal, part + nblk);

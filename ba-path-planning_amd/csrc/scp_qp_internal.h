@@ -14,7 +14,7 @@ enum Slot {  // device scalar slots (doubles)
 struct QpDev {
   // constant blocks
   double *F, *Ft, *S0, *S0t, *HS, *Hf, *Minv, *aug, *wrow;
-  double* MS;  // [2K][K]: [H_f^{-1} ; S0 H_f^{-1}]
+  double* MS;  // [2K + Rf][K]: [H_f^{-1} ; S0 H_f^{-1} ; F H_f^{-1}]
   // the same blocks in MFMA A-operand order for the column-block kernels (scp_qp_pack_operands):
   // [row tile][k step][lane] = A[16 tile + (lane & 15)][4 step + (lane >> 4)], zero beyond the matrix, so that one
   // wave-wide operand load is 512 contiguous bytes
@@ -32,6 +32,7 @@ struct QpDev {
   double* scal;   // SL_COUNT
   double* part;   // 2 * SCP_PART_CAP
   double* hpf;    // [K][C]: H_f p of the fused PCG
+  double* fx;     // [Rf][C]: F x carried by the single-step pipeline (F p goes to tf)
   double* dyf;    // [Rf][C]: snapshot of y_f, then delta-y (primal infeasibility certificate)
   double* dyc;    // [cap]  : same for the working rows
   // deterministic row -> column transfer (single-step pipeline): incidence lists per (time step, agent) cell
@@ -53,7 +54,8 @@ struct scp_qp {
   bool problem_set, reset_done;
   bool cg1_ready;  // carried state (Qx, gval) of the single-step pipeline matches (x, zc, yc, rho)
   bool csr_valid;  // incidence lists match the working set
-  bool qx_fresh;   // the Qx slab holds S0 x exactly (written by the fused residual kernel)
+  bool qx_fresh;   // the current S0 x buffer and the F x slab are exact for x (written by the fused residual kernel)
+  int qx_sel;      // which half of HQ holds S0 x (the single-step pipeline ping-pongs: 0 -> rows [K, 2K), 1 -> [0, K))
   double* h_part;  // pinned, SCP_PART_CAP doubles: per-workgroup partial sums read back at a termination check
   double rho;
   QpDev d;
@@ -76,5 +78,5 @@ int scp_qp_csr_build(scp_qp* qp);
 int scp_qp_pack_operands(scp_qp* qp);
 static inline size_t scp_packed_count(int R, int M) { return (size_t)((R + 15) / 16) * ((M + 3) / 4) * 64; }
 // Termination-check quantities of the single-step pipeline in 3 launches (row values, column blocks, rows):
-// fills qp->h_scal[SL_RP .. SL_SUPP] like residuals() in scp_qp.hip and leaves S0 x in the Qx slab.  Synchronises.
+// fills qp->h_scal[SL_RP .. SL_SUPP] like residuals() in scp_qp.hip and leaves S0 x and F x in their slabs.  Synchronises.
 int scp_qp_fused_residuals(scp_qp* qp, bool with_dy);

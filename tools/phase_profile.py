@@ -17,8 +17,8 @@ from path_planning import _hip  # noqa: E402
 from path_planning.scenarios.position_generator import generate_grid_swap  # noqa: E402
 from path_planning.solvers.scp import SCP  # noqa: E402
 
-COLA = ["load x / gather G / build W", "phase A: F^T W | H_f x | S0^T G", "r", "phase B: [Minv; S0 Minv] r", "r.p", "store p, Qp"]
-POST = ["sum partials", "x~ = x + a p", "F x~ | S0 x~", "z_f, y_f update", "x, Qt, Qx update"]
+COLA = ["prologue: operand prefetch, x / F x / z / y, gather G", "r: reverse scans (one wave per column)",
+        "p = Minv r (MFMA)", "S0 p, F p: forward scans, r.p", "stores p, S0 p, F p"]
 
 
 def main():
@@ -35,15 +35,10 @@ def main():
     buf = (C.c_ulonglong * 64)()
     assert lib.scp_debug_phase_clocks(buf, 64) == 0
     t = list(buf)
-    print("cg1_colA_kernel (10 ns ticks):")
+    print("cg1_col_kernel, middle workgroup (10 ns ticks):")
     for i, name in enumerate(COLA):
-        print(f"  {name:36s} {(t[i + 1] - t[i]) * 0.01:7.2f} us")
-    print(f"  total inside the workgroup           {(t[6] - t[0]) * 0.01:7.2f} us")
-    print("cg1_post_kernel:")
-    for i, name in enumerate(POST):
-        print(f"  {name:36s} {(t[17 + i] - t[16 + i]) * 0.01:7.2f} us")
-    print(f"  total inside the workgroup           {(t[21] - t[16]) * 0.01:7.2f} us")
-    print(f"  (warm repeat of F x~ | S0 x~          {(t[24] - t[19]) * 0.01:7.2f} us, included in the next phase above)")
+        print(f"  {name:56s} {(t[i + 1] - t[i]) * 0.01:7.2f} us")
+    print(f"  {'total inside the workgroup':56s} {(t[5] - t[0]) * 0.01:7.2f} us")
 
 
 if __name__ == "__main__":

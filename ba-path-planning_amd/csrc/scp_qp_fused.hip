@@ -490,9 +490,29 @@ __device__ inline void tile_product(const double* __restrict__ P, int R, int nks
 
 // ---- wave-wide prefix sums over the time index (one wave per column, lane l holds the E consecutive steps
 // k = l E + e): the integrator blocks V, S, S0 and their transposes are first and second cumulative sums ------------
+// data-parallel-primitive moves (no LDS round trip, unlike __shfl): lanes without a source read 0
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_mov0(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// inclusive sum over the 64 lanes: row_shr 1, 2, 4, 8, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2, 3
+__device__ inline double wave_incl_sum(double v) {
+  v += dpp_mov0<0x111, 0xF>(v);
+  v += dpp_mov0<0x112, 0xF>(v);
+  v += dpp_mov0<0x114, 0xF>(v);
+  v += dpp_mov0<0x118, 0xF>(v);
+  v += dpp_mov0<0x142, 0xA>(v);
+  v += dpp_mov0<0x143, 0xC>(v);
+  return v;
+}
+__device__ inline double lane_below(double v) { return dpp_mov0<0x138, 0xF>(v); }  // wave_shr:1 (lane 0 <- 0)
+__device__ inline double lane_above(double v) { return dpp_mov0<0x130, 0xF>(v); }  // wave_shl:1 (lane 63 <- 0)
+
+// inclusive and exclusive prefix sums over the index i = lane E + e (ascending)
 template <int E>
-__device__ inline void wave_scan_fwd(const double (&v)[E], double (&incl)[E], double (&excl)[E]) {
-  const int lane = threadIdx.x & 63;
+__device__ inline void wave_scan(const double (&v)[E], double (&incl)[E], double (&excl)[E]) {
   double run = 0.0;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -500,58 +520,23 @@ __device__ inline void wave_scan_fwd(const double (&v)[E], double (&incl)[E], do
     run += v[e];
     incl[e] = run;
   }
-  double t = run;  // inclusive scan of the lane totals
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const double y = __shfl_up(t, o);
-    if (lane >= o) t += y;
-  }
-  double off = __shfl_up(t, 1);  // total of the lower lanes
-  if (lane == 0) off = 0.0;
+  const double off = lane_below(wave_incl_sum(run));  // total of the lower lanes
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     incl[e] += off;
     excl[e] += off;
   }
 }
-template <int E>
-__device__ inline void wave_scan_rev(const double (&v)[E], double (&incl)[E], double (&excl)[E]) {
-  const int lane = threadIdx.x & 63;
-  double run = 0.0;
-#pragma unroll
-  for (int e = E - 1; e >= 0; --e) {
-    excl[e] = run;
-    run += v[e];
-    incl[e] = run;
-  }
-  double t = run;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const double y = __shfl_down(t, o);
-    if (lane + o < 64) t += y;
-  }
-  double off = __shfl_down(t, 1);  // total of the higher lanes
-  if (lane == 63) off = 0.0;
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    incl[e] += off;
-    excl[e] += off;
-  }
-}
-// value of the previous / next time step (0 outside)
+// value at index i - 1 / i + 1 (0 outside)
 template <int E>
 __device__ inline void wave_prev(const double (&v)[E], double (&o)[E]) {
-  double y = __shfl_up(v[E - 1], 1);
-  if ((threadIdx.x & 63) == 0) y = 0.0;
-  o[0] = y;
+  o[0] = lane_below(v[E - 1]);
 #pragma unroll
   for (int e = 1; e < E; ++e) o[e] = v[e - 1];
 }
 template <int E>
 __device__ inline void wave_next(const double (&v)[E], double (&o)[E]) {
-  double y = __shfl_down(v[0], 1);
-  if ((threadIdx.x & 63) == 63) y = 0.0;
-  o[E - 1] = y;
+  o[E - 1] = lane_above(v[0]);
 #pragma unroll
   for (int e = 0; e + 1 < E; ++e) o[e] = v[e + 1];
 }
@@ -635,14 +620,15 @@ __global__ __launch_bounds__(FT) void cg1_col_kernel(int K, int Rf, int64_t C, d
   }
   __syncthreads();
   PHASE_MARK(1);
-  // ---- r: one wave per column --------------------------------------------------------------------------------
-  double rr[E];
+  // ---- r: one wave per column; index i = lane E + e runs over the time steps in DESCENDING order (k = KM - i), so the
+  // reverse cumulative sums of the transposed integrator blocks are ascending scans over the lanes ----------------
   {
     const double* Wc = Wt + wave * RSF;
+    const int KM = 64 * E - 1;
     double wj[E], wa[E], u1[E], u2[E], g[E], xk[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const int k = lane * E + e;
+      const int k = KM - (lane * E + e);
       const bool ok = k < K;
       wj[e] = k < K - 1 ? Wc[k] : 0.0;
       wa[e] = ok ? Wc[K - 1 + k] : 0.0;
@@ -654,15 +640,15 @@ __global__ __launch_bounds__(FT) void cg1_col_kernel(int K, int Rf, int64_t C, d
       u2[e] = wp + g[e];
     }
     double d1[E], d2[E], s1[E], s2[E], wjp[E];
-    wave_scan_rev<E>(u1, d1, s1);   // d1 = rsum(u1)
-    wave_scan_rev<E>(u2, s1, s2);   // s1 = rsum(u2)
-    wave_scan_rev<E>(s1, s2, d2);   // d2 = rsum_excl(rsum(u2))
-    wave_prev<E>(wj, wjp);
+    wave_scan<E>(u1, d1, s1);   // d1 = rsum(u1)
+    wave_scan<E>(u2, s1, s2);   // s1 = rsum(u2)
+    wave_scan<E>(s1, s2, d2);   // d2 = rsum_excl(rsum(u2))
+    wave_next<E>(wj, wjp);      // w_j[k - 1]
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const int k = lane * E + e;
-      rr[e] = (((wjp[e] - wj[e]) / h + wa[e]) + (d1[e] + 0.5 * hh * g[e]) + hh * d2[e]) - 2.0 * xk[e];
-      if (k < K) Rt[wave * RSK + k] = rr[e];
+      const int k = KM - (lane * E + e);
+      const double rk = (((wjp[e] - wj[e]) / h + wa[e]) + (d1[e] + 0.5 * hh * g[e]) + hh * d2[e]) - 2.0 * xk[e];
+      if (k < K) Rt[wave * RSK + k] = rk;
     }
   }
   __syncthreads();
@@ -703,10 +689,10 @@ __global__ __launch_bounds__(FT) void cg1_col_kernel(int K, int Rf, int64_t C, d
     for (int e = 0; e < E; ++e) {
       const int k = lane * E + e;
       pk[e] = k < K ? Pt[wave * RSK + k] : 0.0;
-      rz += rr[e] * pk[e];
+      rz += (k < K ? Rt[wave * RSK + k] : 0.0) * pk[e];
     }
-    wave_scan_fwd<E>(pk, c1, t1);   // c1 = csum(p)
-    wave_scan_fwd<E>(c1, t2, c2);   // c2 = csum_excl(csum(p))
+    wave_scan<E>(pk, c1, t1);   // c1 = csum(p)
+    wave_scan<E>(c1, t2, c2);   // c2 = csum_excl(csum(p))
     wave_prev<E>(c1, c1p);
     wave_next<E>(pk, pn);
 #pragma unroll

@@ -318,22 +318,57 @@ __global__ __launch_bounds__(256) void max_abs_kernel(int64_t n, const double* _
   if (threadIdx.x == 0) atomic_max_nonneg(slot, mx);
 }
 
-// Hf[a][b] = (2 + sigma) delta_ab + rho * sum_r w_r F[r][a] F[r][b];  HS = [Hf ; S0]
-__global__ __launch_bounds__(256) void build_hf_kernel(int K, int Rf, double rho, double sigma,
-                                                        const double* __restrict__ F, const double* __restrict__ wrow,
-                                                        const double* __restrict__ S0, double* __restrict__ Hf,
-                                                        double* __restrict__ HS, double* __restrict__ aug) {
+// G0[a][b] = sum_r w_r F[r][a] F[r][b]  (constant per problem shape: once at create)
+__global__ __launch_bounds__(256) void build_g0_kernel(int K, int Rf, const double* __restrict__ F,
+                                                        const double* __restrict__ wrow, double* __restrict__ G0) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= K * K) return;
   const int a = t / K, b = t % K;
   double s = 0.0;
   for (int r = 0; r < Rf; ++r) s += wrow[r] * F[(int64_t)r * K + a] * F[(int64_t)r * K + b];
-  const double v = rho * s + (a == b ? 2.0 + sigma : 0.0);
+  G0[t] = s;
+}
+
+// Hf[a][b] = (2 + sigma) delta_ab + rho G0[a][b];  HS = [Hf ; S0];  aug = [Hf | I]
+__global__ __launch_bounds__(256) void build_hf_kernel(int K, double rho, double sigma, const double* __restrict__ G0,
+                                                        const double* __restrict__ S0, double* __restrict__ Hf,
+                                                        double* __restrict__ HS, double* __restrict__ aug) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= K * K) return;
+  const int a = t / K, b = t % K;
+  const double v = rho * G0[t] + (a == b ? 2.0 + sigma : 0.0);
   Hf[t] = v;
   HS[t] = v;
   HS[K * K + t] = S0[t];
   aug[(int64_t)a * 2 * K + b] = v;
   aug[(int64_t)a * 2 * K + K + b] = a == b ? 1.0 : 0.0;
+}
+
+// Gauss-Jordan inverse with [Hf | I] resident in LDS (K <= SCP_INV_LDS_MAX_K); same operations as the global one
+__global__ __launch_bounds__(1024) void spd_inverse_lds_kernel(int K, const double* __restrict__ Hf, double* __restrict__ Minv) {
+  extern __shared__ double sh[];  // aug[K][2K] | prow[2K] | col[K]
+  const int W = 2 * K;
+  double* aug = sh;
+  double* prow = aug + K * W;
+  double* col = prow + W;
+  for (int e = threadIdx.x; e < K * W; e += blockDim.x) {
+    const int r = e / W, c = e % W;
+    aug[e] = c < K ? Hf[r * K + c] : (c - K == r ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  for (int p = 0; p < K; ++p) {
+    const double piv = aug[p * W + p];
+    for (int c = threadIdx.x; c < W; c += blockDim.x) prow[c] = aug[p * W + c] / piv;
+    for (int r = threadIdx.x; r < K; r += blockDim.x) col[r] = aug[r * W + p];
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * W; e += blockDim.x) {
+      const int r = e / W, c = e % W;
+      if (r == p) aug[e] = prow[c];
+      else aug[e] -= col[r] * prow[c];
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < K * K; e += blockDim.x) Minv[e] = aug[(e / K) * W + K + (e % K)];
 }
 
 // Gauss-Jordan inverse of the SPD matrix held in aug = [Hf | I] (K x 2K, global memory, one workgroup).
@@ -425,14 +460,13 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.Minv = c.take<double>((size_t)K * K);
   d.aug = c.take<double>((size_t)2 * K * K);
   d.wrow = c.take<double>((size_t)Rf);
-  d.MS = c.take<double>((size_t)(2 * K + Rf) * K);
+  d.G0 = c.take<double>((size_t)K * K);
   d.pF = c.take<double>(scp_packed_count(Rf, K));
   d.pFt = c.take<double>(scp_packed_count(K, Rf));
   d.pS0 = c.take<double>(scp_packed_count(K, K));
   d.pS0t = c.take<double>(scp_packed_count(K, K));
   d.pHS = c.take<double>(scp_packed_count(2 * K, K));
   d.pMinv = c.take<double>(scp_packed_count(K, K));
-  d.pMS = c.take<double>(scp_packed_count(2 * K + Rf, K));
   const size_t nf = (size_t)Rf * C, nx = (size_t)K * C;
   d.lf = c.take<double>(nf);
   d.uf = c.take<double>(nf);
@@ -456,7 +490,7 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.w_l = c.take<double>((size_t)cap);
   d.zc = c.take<double>((size_t)cap);
   d.yc = c.take<double>((size_t)cap);
-  d.scal = c.take<double>(SL_COUNT);
+  d.scal = c.take<double>(SL_COUNT + SCP_PART_CAP);
   d.part = c.take<double>(2 * SCP_PART_CAP);
   d.hpf = c.take<double>(nx);
   d.fx = c.take<double>(nf);
@@ -526,15 +560,19 @@ int build_kkt(scp_qp* qp) {
   const QpDev& d = qp->d;
   const int K = qp->K;
   hipStream_t s = qp->ctx->stream;
-  hipLaunchKernelGGL(build_hf_kernel, grid1((int64_t)K * K), dim3(256), 0, s, K, qp->Rf, qp->rho, qp->st.sigma, d.F,
-                     d.wrow, d.S0, d.Hf, d.HS, d.aug);
+  hipLaunchKernelGGL(build_hf_kernel, grid1((int64_t)K * K), dim3(256), 0, s, K, qp->rho, qp->st.sigma, d.G0, d.S0, d.Hf,
+                     d.HS, d.aug);
   QP_LAUNCHED(qp);
-  hipLaunchKernelGGL(spd_inverse_kernel, dim3(1), dim3(1024), (size_t)3 * K * sizeof(double), s, K, d.aug, d.Minv);
+  if (K <= SCP_INV_LDS_MAX_K) {
+    const size_t lds = ((size_t)K * 2 * K + 3 * K) * sizeof(double);
+    if (lds > 64 * 1024)
+      SCP_HIP_CHECK(qp->ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(spd_inverse_lds_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(spd_inverse_lds_kernel, dim3(1), dim3(1024), lds, s, K, d.Hf, d.Minv);
+  } else {
+    hipLaunchKernelGGL(spd_inverse_kernel, dim3(1), dim3(1024), (size_t)3 * K * sizeof(double), s, K, d.aug, d.Minv);
+  }
   QP_LAUNCHED(qp);
-  // MS = [Minv ; S0 Minv ; F Minv]: p, S0 p and F p from one product in the single-step pipeline
-  SCP_HIP_CHECK(qp->ctx, hipMemcpyAsync(d.MS, d.Minv, (size_t)K * K * sizeof(double), hipMemcpyDeviceToDevice, s));
-  QP_CHECK(scp_launch_gemm(qp->ctx, 1, K, K, K, 1.0, d.S0, d.Minv, 0.0, d.MS + (size_t)K * K));
-  QP_CHECK(scp_launch_gemm(qp->ctx, 1, qp->Rf, K, K, 1.0, d.F, d.Minv, 0.0, d.MS + (size_t)2 * K * K));
   return scp_qp_pack_operands(qp);
 }
 
@@ -722,8 +760,7 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
   qp->qx_sel = 0;
   qp->rho = s->rho;
   carve(qp->d, workspace, K, qp->C, row_capacity, D);
-  if (hipHostMalloc(&qp->h_scal, SL_COUNT * sizeof(double)) != hipSuccess ||
-      hipHostMalloc(&qp->h_part, SCP_PART_CAP * sizeof(double)) != hipSuccess) {
+  if (hipHostMalloc(&qp->h_scal, (SL_COUNT + SCP_PART_CAP) * sizeof(double)) != hipSuccess) {
     delete qp;
     return scp_fail(ctx, SCP_ERR_HIP, "qp_create: hipHostMalloc failed");
   }
@@ -758,9 +795,14 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
             hipStreamSynchronize(st) == hipSuccess;
   if (!ok) {
     (void)hipHostFree(qp->h_scal);
-    (void)hipHostFree(qp->h_part);
     delete qp;
     return scp_fail(ctx, SCP_ERR_HIP, "qp_create: constant upload failed");
+  }
+  hipLaunchKernelGGL(build_g0_kernel, grid1((int64_t)K * K), dim3(256), 0, st, K, Rf, d.F, d.wrow, d.G0);
+  if (hipGetLastError() != hipSuccess) {
+    (void)hipHostFree(qp->h_scal);
+    delete qp;
+    return scp_fail(ctx, SCP_ERR_HIP, "qp_create: launch failed");
   }
   *out = qp;
   return SCP_OK;
@@ -770,7 +812,6 @@ extern "C" void scp_qp_destroy(scp_qp* qp) {
   if (!qp) return;
   (void)hipStreamSynchronize(qp->ctx->stream);
   (void)hipHostFree(qp->h_scal);
-  (void)hipHostFree(qp->h_part);
   delete qp;
 }
 
@@ -853,20 +894,19 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
     ++it;
     const bool will_check = it % st.check_termination == 0 || it >= st.max_iter;
     const bool with_dy = will_check && st.eps_prim_inf > 0.0;
-    if (with_dy) {  // snapshot of the duals: delta-y of this iteration feeds the infeasibility certificate
+    const bool cg1_it = fused && st.cg_iters == 1 && qp->nW > 0;  // its update kernel emits delta-y itself
+    if (with_dy && !cg1_it) {  // snapshot of the duals: delta-y of this iteration feeds the infeasibility certificate
       SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->d.dyf, qp->d.yf, (size_t)qp->Rf * qp->C * sizeof(double),
                                         hipMemcpyDeviceToDevice, ctx->stream));
       if (qp->nW > 0)
         SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->d.dyc, qp->d.yc, (size_t)qp->nW * sizeof(double),
                                           hipMemcpyDeviceToDevice, ctx->stream));
     }
-    if (fused && st.cg_iters == 1 && qp->nW > 0) QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total));
+    if (cg1_it) QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total, with_dy));
     else if (fused) QP_CHECK(scp_qp_fused_iteration(qp, &cg_total));
     else QP_CHECK(admm_iteration(qp, &cg_total));
     if (will_check) {
-      const bool cg1 = fused && st.cg_iters == 1 && qp->nW > 0 && qp->csr_valid &&
-                       (qp->C + 15) / 16 + 128 <= SCP_PART_CAP;
-      if (cg1) QP_CHECK(scp_qp_fused_residuals(qp, with_dy));
+      if (cg1_it) QP_CHECK(scp_qp_fused_residuals(qp, with_dy ? 2 : 0));
       else QP_CHECK(residuals(qp, with_dy));
       qp->cg1_ready = false;  // the check used gval / G and the Q slabs as scratch; rho may change below
       const double* hs = qp->h_scal;

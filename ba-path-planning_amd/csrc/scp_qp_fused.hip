@@ -10,6 +10,7 @@
 // An ADMM step with n PCG steps is 4n + 3 launches, 7 at the default n = 1 (15n + ... on the generic path of scp_qp.hip, which stays as the fallback
 // for K > 128 and as the use_mfma = 0/2 reference); the arithmetic is the same, statement by statement.
 #include "scp_qp_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -774,10 +775,10 @@ __device__ inline double step_length_256(const double* __restrict__ part_rz, int
   return (pHp > 0.0 && rz != 0.0) ? rz / pHp : 0.0;
 }
 
-constexpr int UPD_SEG = 16;  // row segments per 16-column block in the elementwise part of cg1_update_kernel
+constexpr int UPD_RPT = 2;  // slab rows per thread in the elementwise part of cg1_update_kernel (32 rows per workgroup)
 
-// Launch 3 of 3: everything that follows the step length, elementwise.  Workgroups [0, eblocks): a sixteenth of
-// the slab rows of ONE 16-column block each -- fixed rows: F x~ = F x + a F p, z/y update, F x += alpha a F p; x rows:
+// Launch 3 of 3: everything that follows the step length, elementwise.  Workgroups [0, eblocks): 32 slab
+// rows of ONE 16-column block each -- fixed rows: F x~ = F x + a F p, z/y update, F x += alpha a F p; x rows:
 // x += alpha a p, S0 x (new buffer) = S0 x + alpha a S0 p.  Workgroup w works on column block w % nblk8 (nblk8 =
 // nblk rounded up to a multiple of 8): workgroups go round-robin over the 8 XCDs, so the slabs are rewritten in the L2
 // of the XCD whose cg1_col_kernel workgroup reads them next (a row-major split left every read a remote miss: 8 us
@@ -799,56 +800,86 @@ __global__ __launch_bounds__(256) void cg1_update_kernel(int K, int Rf, int64_t 
                                                           const double* __restrict__ weta, const double* __restrict__ wl,
                                                           double* __restrict__ zc, double* __restrict__ yc,
                                                           const int* __restrict__ pos_i, const int* __restrict__ pos_j,
-                                                          double* __restrict__ gval) {
-  const double a = step_length_256(part_rz, nblk, part_sq);
-  const double aa = alpha * a;
+                                                          double* __restrict__ gval, double* __restrict__ dyf,
+                                                          double* __restrict__ dyc) {
+  // all operands are loaded BEFORE the step length is reduced (one memory round trip for both)
   if ((int)blockIdx.x < eblocks) {
     const int seg = blockIdx.x / nblk8, blk = blockIdx.x - seg * nblk8;
     const int64_t col = (int64_t)blk * CB + (threadIdx.x & 15);
-    if (blk >= nblk || col >= C) return;
+    const bool live = blk < nblk && col < C;
     const int rows = Rf + K;
-    const int r1 = rows * (seg + 1) / UPD_SEG;
-    for (int row = rows * seg / UPD_SEG + (threadIdx.x >> 4); row < r1; row += 16) {
-      if (row < Rf) {
-        const double rr = rho * wrow[row];
+    double v0[UPD_RPT], v1[UPD_RPT], v2[UPD_RPT], v3[UPD_RPT], v4[UPD_RPT], v5[UPD_RPT], rr[UPD_RPT];
+#pragma unroll
+    for (int u = 0; u < UPD_RPT; ++u) {
+      const int row = seg * (16 * UPD_RPT) + u * 16 + (threadIdx.x >> 4);
+      v0[u] = v1[u] = v2[u] = v3[u] = v4[u] = v5[u] = 0.0;
+      rr[u] = 1.0;
+      if (live && row < Rf) {
         const int64_t g = (int64_t)row * C + col;
-        const double fx = Fx[g], fp = Fp[g];
-        const double zh = alpha * fma(a, fp, fx) + (1.0 - alpha) * zf[g];
-        const double y = yf[g];
-        const double zn = fmin(fmax(zh + y / rr, lf[g]), uf[g]);
-        yf[g] = y + rr * (zh - zn);
-        zf[g] = zn;
-        Fx[g] = fma(aa, fp, fx);
-      } else {
+        v0[u] = Fx[g]; v1[u] = Fp[g]; v2[u] = zf[g]; v3[u] = yf[g]; v4[u] = lf[g]; v5[u] = uf[g];
+        rr[u] = rho * wrow[row];
+      } else if (live && row < rows) {
         const int64_t g = (int64_t)(row - Rf) * C + col;
-        x[g] = fma(aa, pdir[g], x[g]);
-        Qn[g] = fma(aa, Qp[g], Qx[g]);
+        v0[u] = x[g]; v1[u] = pdir[g]; v2[u] = Qx[g]; v3[u] = Qp[g];
+      }
+    }
+    const double a = step_length_256(part_rz, nblk, part_sq);
+    const double aa = alpha * a;
+    if (!live) return;
+#pragma unroll
+    for (int u = 0; u < UPD_RPT; ++u) {
+      const int row = seg * (16 * UPD_RPT) + u * 16 + (threadIdx.x >> 4);
+      if (row < Rf) {
+        const int64_t g = (int64_t)row * C + col;
+        const double zh = alpha * fma(a, v1[u], v0[u]) + (1.0 - alpha) * v2[u];
+        const double y = v3[u];
+        const double zn = fmin(fmax(zh + y / rr[u], v4[u]), v5[u]);
+        const double yn = y + rr[u] * (zh - zn);
+        yf[g] = yn;
+        zf[g] = zn;
+        Fx[g] = fma(aa, v1[u], v0[u]);
+        if (dyf) dyf[g] = yn - y;  // delta-y of this iteration (primal infeasibility certificate)
+      } else if (row < rows) {
+        const int64_t g = (int64_t)(row - Rf) * C + col;
+        x[g] = fma(aa, v1[u], v0[u]);
+        Qn[g] = fma(aa, v3[u], v2[u]);
       }
     }
     return;
   }
   const int64_t n = (int64_t)(blockIdx.x - eblocks) * 256 + threadIdx.x;
-  if (n >= nW) return;
-  const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
-  const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
+  const bool live = n < nW;
+  double e[D], qi[D], qj[D], pi[D], pj[D], z = 0.0, y = 0.0, lo = 0.0;
+  int posi = 0, posj = 0;
+  if (live) {
+    const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
+    const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      e[d] = weta[n * D + d];
+      qi[d] = Qx[bi + d]; qj[d] = Qx[bj + d]; pi[d] = Qp[bi + d]; pj[d] = Qp[bj + d];
+    }
+    z = zc[n]; y = yc[n]; lo = wl[n];
+    posi = pos_i[n]; posj = pos_j[n];
+  }
+  const double a = step_length_256(part_rz, nblk, part_sq);
+  const double aa = alpha * a;
+  if (!live) return;
   double tc = 0.0, ax = 0.0;
 #pragma unroll
   for (int d = 0; d < D; ++d) {
-    const double e = weta[n * D + d];
-    const double qi = Qx[bi + d], qj = Qx[bj + d], pi = Qp[bi + d], pj = Qp[bj + d];
-    tc += e * (fma(a, pi, qi) - fma(a, pj, qj));
-    ax += e * (fma(aa, pi, qi) - fma(aa, pj, qj));
+    tc += e[d] * (fma(a, pi[d], qi[d]) - fma(a, pj[d], qj[d]));
+    ax += e[d] * (fma(aa, pi[d], qi[d]) - fma(aa, pj[d], qj[d]));
   }
-  double z = zc[n], y = yc[n];
   const double zh = alpha * tc + (1.0 - alpha) * z;
-  const double zn = fmax(zh + y / rho_c, wl[n]);
-  y = y + rho_c * (zh - zn);
-  z = zn;
-  yc[n] = y;
-  zc[n] = z;
-  const double g = (rho_c * z - y) - rho_c * ax;
-  gval[pos_i[n]] = g;
-  gval[pos_j[n]] = g;
+  const double zn = fmax(zh + y / rho_c, lo);
+  const double yn = y + rho_c * (zh - zn);
+  yc[n] = yn;
+  zc[n] = zn;
+  if (dyc) dyc[n] = fmin(yn - y, 0.0);  // u = +inf: projected onto the polar of the recession cone
+  const double g = (rho_c * zn - yn) - rho_c * ax;
+  gval[posi] = g;
+  gval[posj] = g;
 }
 
 // row values of the first right-hand side after (x, zc, yc, rho) changed outside the pipeline (S0 x exact in Qx)
@@ -1005,8 +1036,10 @@ int scp_qp_cg1_prepare(scp_qp* qp) {
 
 // One ADMM iteration with a single preconditioned CG step from x, in three launches: column blocks (r, then
 // [p ; S0 p ; F p]), collision rows (p.H p), elementwise update of every row and column (ping-pong of S0 x).
-int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count) {
+int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count, bool emit_dy) {
   const QpDev& d = qp->d;
+  double* dyf = emit_dy ? d.dyf : nullptr;  // delta-y of this iteration, consumed by scp_qp_fused_residuals(.., 2)
+  double* dyc = emit_dy ? d.dyc : nullptr;
   hipStream_t s = qp->ctx->stream;
   const int K = qp->K, Rf = qp->Rf;
   const int64_t C = qp->C, nx = (int64_t)K * C;
@@ -1044,16 +1077,16 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count) {
                        d.w_eta, Qp, part_sq);
   FUSED_LAUNCHED(qp);
   const int nblk8 = (nblk + 7) & ~7;
-  const int eblocks = nblk8 * UPD_SEG;
+  const int eblocks = nblk8 * ((Rf + K + 16 * UPD_RPT - 1) / (16 * UPD_RPT));
   const dim3 ugrid((unsigned)(eblocks + (qp->nW + 255) / 256));
   if (qp->D == 2)
     hipLaunchKernelGGL(cg1_update_kernel<2>, ugrid, rblock, 0, s, K, Rf, C, nblk, eblocks, nblk8, qp->rho, rho_c, qp->st.alpha,
                        part_rz, part_sq, d.wrow, d.lf, d.uf, d.zf, d.yf, d.fx, Fp, d.x, d.p, Qp, Qx, Qn, qp->nW, d.w_k,
-                       d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
+                       d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc, d.pos_i, d.pos_j, d.gval, dyf, dyc);
   else
     hipLaunchKernelGGL(cg1_update_kernel<3>, ugrid, rblock, 0, s, K, Rf, C, nblk, eblocks, nblk8, qp->rho, rho_c, qp->st.alpha,
                        part_rz, part_sq, d.wrow, d.lf, d.uf, d.zf, d.yf, d.fx, Fp, d.x, d.p, Qp, Qx, Qn, qp->nW, d.w_k,
-                       d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
+                       d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc, d.pos_i, d.pos_j, d.gval, dyf, dyc);
   FUSED_LAUNCHED(qp);
   qp->qx_sel ^= 1;
   ++*cg_count;
@@ -1147,8 +1180,10 @@ __global__ __launch_bounds__(256) void csr_finish_kernel(int64_t nent, int D, co
 __global__ __launch_bounds__(256) void csr_rowval_kernel(int64_t nW, int mode, double rho, const double* __restrict__ zc,
                                                           const double* __restrict__ yc, const double* __restrict__ vec,
                                                           const int* __restrict__ pos_i, const int* __restrict__ pos_j,
-                                                          double* __restrict__ gval) {
+                                                          double* __restrict__ gval, double* __restrict__ zero,
+                                                          int nzero) {
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n < nzero) zero[n] = 0.0;  // reduction slots of the launch that follows
   if (n >= nW) return;
   const double g = mode == 0 ? rho * zc[n] - yc[n] : (mode == 1 ? yc[n] : vec[n]);
   gval[pos_i[n]] = g;
@@ -1198,7 +1233,7 @@ int scp_qp_csr_scatter(scp_qp* qp, int mode, const double* vec) {
   hipStream_t s = qp->ctx->stream;
   const int64_t nx = (int64_t)qp->K * qp->C;
   hipLaunchKernelGGL(csr_rowval_kernel, dim3((unsigned)((qp->nW + 255) / 256)), dim3(256), 0, s, qp->nW, mode,
-                     qp->rho * qp->st.rho_col_scale, d.zc, d.yc, vec, d.pos_i, d.pos_j, d.gval);
+                     qp->rho * qp->st.rho_col_scale, d.zc, d.yc, vec, d.pos_i, d.pos_j, d.gval, (double*)nullptr, 0);
   hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, s, qp->K, qp->N, qp->D,
                      d.cell_ptr, d.coef, d.gval, d.G);
   FUSED_LAUNCHED(qp);
@@ -1215,7 +1250,7 @@ struct PackDesc {
   int R, M;
 };
 struct PackArgs {
-  PackDesc m[7];
+  PackDesc m[6];
 };
 __global__ __launch_bounds__(256) void pack_operands_kernel(PackArgs a) {
   const PackDesc d = a.m[blockIdx.y];
@@ -1241,8 +1276,7 @@ int scp_qp_pack_operands(scp_qp* qp) {
   a.m[3] = {d.S0t, d.pS0t, K, K};
   a.m[4] = {d.HS, d.pHS, 2 * K, K};
   a.m[5] = {d.Minv, d.pMinv, K, K};
-  a.m[6] = {d.MS, d.pMS, 2 * K + Rf, K};
-  hipLaunchKernelGGL(pack_operands_kernel, dim3(16, 7), dim3(256), 0, qp->ctx->stream, a);
+  hipLaunchKernelGGL(pack_operands_kernel, dim3(16, 6), dim3(256), 0, qp->ctx->stream, a);
   FUSED_LAUNCHED(qp);
   return SCP_OK;
 }
@@ -1271,9 +1305,11 @@ __device__ inline void atomic_max_nn(double* addr, double v) {
   atomicMax((unsigned long long*)addr, (unsigned long long)__double_as_longlong(v));
 }
 
-__global__ __launch_bounds__(FT) void cg1_resid_col_kernel(int K, int Rf, int64_t C, int N, int D, int with_dy,
-                                                            const double* __restrict__ F, const double* __restrict__ S0,
-                                                            const double* __restrict__ Ft, const double* __restrict__ S0t,
+// Column part of the check, with the integrator blocks as wave scans like cg1_col_kernel (one wave per column):
+//   F x, S0 x (stored: the pipeline's carried slabs are refreshed exactly), A^T y = F^T y_f + S0^T G(yc), and the
+//   maxima of the primal / dual residuals and of delta-y over this block's 16 columns.
+template <int E>
+__global__ __launch_bounds__(FT) void cg1_resid_col_kernel(int K, int Rf, int64_t C, double h, int N, int D, int with_dy,
                                                             const double* __restrict__ x, const double* __restrict__ zf,
                                                             const double* __restrict__ yf, const double* __restrict__ lf,
                                                             const double* __restrict__ uf, double* __restrict__ dyf,
@@ -1283,71 +1319,114 @@ __global__ __launch_bounds__(FT) void cg1_resid_col_kernel(int K, int Rf, int64_
                                                             double* __restrict__ Fx, double* __restrict__ scal,
                                                             double* __restrict__ part_supp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* X = lds;               // [K][16]
-  double* T = X + K * CB;        // [Rf][16]  F x, then y_f
-  double* Q = T + Rf * CB;       // [K][16]   S0 x
-  double* Gt = Q + K * CB;       // [K][16]   gather of eta * yc
-  double* A1 = Gt + K * CB;      // [K][16]   F^T y (first half of the rows)
-  double* A1b = A1 + K * CB;     // [K][16]   F^T y (second half)
-  double* A2 = A1b + K * CB;     // [K][16]   S0^T G
+  const int RSF = pad_col(Rf), RSK = pad_col(K);
+  double* YF = lds;              // [16][RSF]  y_f, then F x (each column is read and rewritten by its own wave)
+  double* Gx = YF + CB * RSF;    // [16][RSK]  gather of eta * yc
+  double* Xt = Gx + CB * RSK;    // [16][RSK]  x
+  double* Qt = Xt + CB * RSK;    // [16][RSK]  S0 x
   const int64_t c0 = (int64_t)blockIdx.x * CB;
-  tile_load(X, x, K, C, c0);
-  for (int e = threadIdx.x; e < K * CB; e += FT) {
-    const int k = e >> 4, c = e & 15;
-    double acc = 0.0;
-    if (c0 + c < C) {
-      const int col = (int)(c0 + c);
-      const int agent = col / D, d = col - agent * D;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = threadIdx.x & 15, kg = threadIdx.x >> 4;
+  const bool cok = c0 + c < C;
+  const int col = (int)(c0 + c), agent = col / D, dd_ = col - agent * D;
+  const double hh = h * h;
+  double ndy = 0.0, supp = 0.0;
+  for (int k = kg; k < K; k += FT / CB) {
+    double acc = 0.0, xv = 0.0;
+    if (cok) {
       const int cell = k * N + agent;
       const int t1 = cell_ptr[cell + 1];
-      for (int t = cell_ptr[cell]; t < t1; ++t) acc += coef[(size_t)t * D + d] * gval[t];
+      for (int t = cell_ptr[cell]; t < t1; ++t) acc += coef[(size_t)t * D + dd_] * gval[t];
+      xv = x[(int64_t)k * C + c0 + c];
     }
-    Gt[e] = acc;
+    Gx[c * RSK + k] = acc;
+    Xt[c * RSK + k] = xv;
   }
-  __syncthreads();
-  wg_mm<false>(F, Rf, K, X, T, 0, NWV - 3);
-  wg_mm<false>(S0, K, K, X, Q, NWV - 3, 3);
-  __syncthreads();
-  double rp = 0.0, nax = 0.0, nz = 0.0, ndy = 0.0, supp = 0.0;
-  for (int e = threadIdx.x; e < Rf * CB; e += FT) {
-    const int r = e >> 4, c = e & 15;
+  for (int r = kg; r < Rf; r += FT / CB) {
     double y = 0.0;
-    if (c0 + c < C) {
+    if (cok) {
       const int64_t g = (int64_t)r * C + c0 + c;
-      const double a = T[e], z = zf[g];
       y = yf[g];
-      Fx[g] = a;
-      rp = fmax(rp, fabs(a - z));
-      nax = fmax(nax, fabs(a));
-      nz = fmax(nz, fabs(z));
       if (with_dy) {
-        const double dd = y - dyf[g];
-        dyf[g] = dd;
+        const double dd = with_dy == 2 ? dyf[g] : y - dyf[g];  // 2: the update kernel stored delta-y
+        if (with_dy == 1) dyf[g] = dd;
         ndy = fmax(ndy, fabs(dd));
         supp += uf[g] * fmax(dd, 0.0) + lf[g] * fmin(dd, 0.0);
       }
     }
-    T[e] = y;  // same thread read T[e]: the tile now holds y_f
+    YF[c * RSF + r] = y;
   }
-  for (int e = threadIdx.x; e < K * CB; e += FT) {
-    const int r = e >> 4, c = e & 15;
-    if (c0 + c < C) Qx[(int64_t)r * C + c0 + c] = Q[e];
-  }
-  __syncthreads();
-  const int half = ((Rf / 2) + 3) & ~3;
-  wg_mm_range<false>(Ft, K, Rf, 0, half, T, A1, 0, 6);
-  wg_mm_range<false>(Ft, K, Rf, half, Rf, T, A1b, 6, 6);
-  wg_mm<false>(S0t, K, K, Gt, A2, 12, NWV - 12);
   __syncthreads();
   double rd = 0.0, npx = 0.0, nat = 0.0;
-  for (int e = threadIdx.x; e < K * CB; e += FT) {
-    const int c = e & 15;
-    if (c0 + c < C) {
-      const double aty = (A1[e] + A1b[e]) + A2[e], px = 2.0 * X[e];
-      rd = fmax(rd, fabs(px + aty));
-      npx = fmax(npx, fabs(px));
-      nat = fmax(nat, fabs(aty));
+  {
+    double* Yc = YF + wave * RSF;
+    // A^T y over the time steps in descending order (reverse cumulative sums as ascending scans)
+    const int KM = 64 * E - 1;
+    double yj[E], ya[E], u1[E], u2[E], g[E], xk[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int k = KM - (lane * E + e);
+      const bool ok = k < K;
+      yj[e] = k < K - 1 ? Yc[k] : 0.0;
+      ya[e] = ok ? Yc[K - 1 + k] : 0.0;
+      const double yv = ok ? Yc[2 * K - 1 + k] : 0.0;
+      const double yp = ok ? Yc[3 * K - 1 + k] : 0.0;
+      g[e] = ok ? Gx[wave * RSK + k] : 0.0;
+      xk[e] = ok ? Xt[wave * RSK + k] : 0.0;
+      u1[e] = h * yv + 0.5 * hh * (yp - g[e]);
+      u2[e] = yp + g[e];
     }
+    double d1[E], d2[E], s1[E], s2[E], yjp[E];
+    wave_scan<E>(u1, d1, s1);
+    wave_scan<E>(u2, s1, s2);
+    wave_scan<E>(s1, s2, d2);
+    wave_next<E>(yj, yjp);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int k = KM - (lane * E + e);
+      if (k < K) {
+        const double aty = ((yjp[e] - yj[e]) / h + ya[e]) + (d1[e] + 0.5 * hh * g[e]) + hh * d2[e];
+        const double px = 2.0 * xk[e];
+        rd = fmax(rd, fabs(px + aty));
+        npx = fmax(npx, fabs(px));
+        nat = fmax(nat, fabs(aty));
+      }
+    }
+    // F x and S0 x in ascending order (every lane of this wave has read its y_f entries above)
+    double pk[E], c1[E], c2[E], t1[E], t2[E], c1p[E], pn[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int k = lane * E + e;
+      pk[e] = k < K ? Xt[wave * RSK + k] : 0.0;
+    }
+    wave_scan<E>(pk, c1, t1);
+    wave_scan<E>(c1, t2, c2);
+    wave_prev<E>(c1, c1p);
+    wave_next<E>(pk, pn);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int k = lane * E + e;
+      if (k < K) {
+        Qt[wave * RSK + k] = hh * (c2[e] - 0.5 * c1p[e]);
+        if (k < K - 1) Yc[k] = (pn[e] - pk[e]) / h;
+        Yc[K - 1 + k] = pk[e];
+        Yc[2 * K - 1 + k] = h * c1[e];
+        Yc[3 * K - 1 + k] = hh * (c2[e] + 0.5 * c1[e]);
+      }
+    }
+  }
+  __syncthreads();
+  double rp = 0.0, nax = 0.0, nz = 0.0;
+  if (cok) {
+    for (int r = kg; r < Rf; r += FT / CB) {
+      const int64_t g = (int64_t)r * C + c0 + c;
+      const double a = YF[c * RSF + r], z = zf[g];
+      Fx[g] = a;
+      rp = fmax(rp, fabs(a - z));
+      nax = fmax(nax, fabs(a));
+      nz = fmax(nz, fabs(z));
+    }
+    for (int k = kg; k < K; k += FT / CB) Qx[(int64_t)k * C + c0 + c] = Qt[c * RSK + k];
   }
   rp = wg_max(rp); nax = wg_max(nax); nz = wg_max(nz);
   rd = wg_max(rd); npx = wg_max(npx); nat = wg_max(nat);
@@ -1384,8 +1463,8 @@ __global__ __launch_bounds__(256) void cg1_resid_rows_kernel(int64_t nW, int64_t
     nax = fmax(nax, fabs(a));
     nz = fmax(nz, fabs(z));
     if (with_dy) {
-      const double dd = fmin(yc[n] - dyc[n], 0.0);  // u = +inf: projected onto the polar of the recession cone
-      dyc[n] = dd;
+      const double dd = with_dy == 2 ? dyc[n] : fmin(yc[n] - dyc[n], 0.0);  // u = +inf: polar of the recession cone
+      if (with_dy == 1) dyc[n] = dd;
       ndy = fmax(ndy, fabs(dd));
       supp += wl[n] * dd;
     }
@@ -1409,38 +1488,43 @@ __global__ __launch_bounds__(256) void cg1_resid_rows_kernel(int64_t nW, int64_t
 
 }  // namespace
 
-int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
+int scp_qp_fused_residuals(scp_qp* qp, int with_dy) {
   const QpDev& d = qp->d;
   scp_ctx* ctx = qp->ctx;
   hipStream_t s = ctx->stream;
   const int K = qp->K, Rf = qp->Rf;
   const int64_t C = qp->C, nx = (int64_t)K * C;
   const int nblk = (int)((C + CB - 1) / CB);
-  const size_t tile = (size_t)CB * sizeof(double);
   double* Qx = qp->qx_sel ? d.HQ : d.HQ + nx;
-  double* part = d.part;  // [0, nblk): column blocks, [nblk, nblk + RESID_ROW_BLOCKS): row blocks
-  SCP_HIP_CHECK(ctx, hipMemsetAsync(d.scal + SL_RP, 0, 9 * sizeof(double), s));
+  double* part = d.scal + SL_COUNT;  // [0, nblk): column blocks, [nblk, nblk + RESID_ROW_BLOCKS): row blocks
+  // gval = yc and the maxima slots zeroed (one launch)
   hipLaunchKernelGGL(csr_rowval_kernel, dim3((unsigned)((qp->nW + 255) / 256)), dim3(256), 0, s, qp->nW, 1, 0.0, d.zc,
-                     d.yc, (const double*)nullptr, d.pos_i, d.pos_j, d.gval);
-  const size_t lds = (size_t)(Rf + 6 * K) * tile;
-  int rc = allow_lds(qp, cg1_resid_col_kernel, lds);
-  if (rc) return rc;
-  hipLaunchKernelGGL(cg1_resid_col_kernel, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->N, qp->D, with_dy ? 1 : 0, d.pF,
-                     d.pS0, d.pFt, d.pS0t, d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval, Qx, d.fx, d.scal, part);
+                     d.yc, (const double*)nullptr, d.pos_i, d.pos_j, d.gval, d.scal + SL_RP, 9);
+  const size_t lds = (size_t)CB * (pad_col(Rf) + 3 * pad_col(K)) * sizeof(double);
+  if (K <= 64) {
+    int rc = allow_lds(qp, cg1_resid_col_kernel<1>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cg1_resid_col_kernel<1>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->h, qp->N, qp->D, with_dy, d.x,
+                       d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval, Qx, d.fx, d.scal, part);
+  } else {
+    int rc = allow_lds(qp, cg1_resid_col_kernel<2>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cg1_resid_col_kernel<2>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->h, qp->N, qp->D, with_dy, d.x,
+                       d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval, Qx, d.fx, d.scal, part);
+  }
   if (qp->D == 2)
-    hipLaunchKernelGGL(cg1_resid_rows_kernel<2>, dim3(RESID_ROW_BLOCKS), dim3(256), 0, s, qp->nW, C, with_dy ? 1 : 0, d.w_k,
+    hipLaunchKernelGGL(cg1_resid_rows_kernel<2>, dim3(RESID_ROW_BLOCKS), dim3(256), 0, s, qp->nW, C, with_dy, d.w_k,
                        d.w_i, d.w_j, d.w_eta, d.w_l, Qx, d.zc, d.yc, d.dyc, d.scal, part + nblk);
   else
-    hipLaunchKernelGGL(cg1_resid_rows_kernel<3>, dim3(RESID_ROW_BLOCKS), dim3(256), 0, s, qp->nW, C, with_dy ? 1 : 0, d.w_k,
+    hipLaunchKernelGGL(cg1_resid_rows_kernel<3>, dim3(RESID_ROW_BLOCKS), dim3(256), 0, s, qp->nW, C, with_dy, d.w_k,
                        d.w_i, d.w_j, d.w_eta, d.w_l, Qx, d.zc, d.yc, d.dyc, d.scal, part + nblk);
   FUSED_LAUNCHED(qp);
-  SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->h_scal, d.scal, SL_COUNT * sizeof(double), hipMemcpyDeviceToHost, s));
-  SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->h_part, part, (size_t)(nblk + RESID_ROW_BLOCKS) * sizeof(double),
-                                    hipMemcpyDeviceToHost, s));
+  const int npart = nblk + RESID_ROW_BLOCKS;  // partials follow the scalar slots: one copy
+  SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->h_scal, d.scal, (size_t)(SL_COUNT + npart) * sizeof(double), hipMemcpyDeviceToHost, s));
   SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));
   double supp = 0.0;
   if (with_dy)
-    for (int b = 0; b < nblk + RESID_ROW_BLOCKS; ++b) supp += qp->h_part[b];
+    for (int b = 0; b < npart; ++b) supp += qp->h_scal[SL_COUNT + b];
   qp->h_scal[SL_SUPP] = supp;
   qp->qx_fresh = true;
   return SCP_OK;

@@ -14,11 +14,11 @@ enum Slot {  // device scalar slots (doubles)
 struct QpDev {
   // constant blocks
   double *F, *Ft, *S0, *S0t, *HS, *Hf, *Minv, *aug, *wrow;
-  double* MS;  // [2K + Rf][K]: [H_f^{-1} ; S0 H_f^{-1} ; F H_f^{-1}]
+  double* G0;  // [K][K]: F^T w F (constant; H_f = (2 + sigma) I + rho G0)
   // the same blocks in MFMA A-operand order for the column-block kernels (scp_qp_pack_operands):
   // [row tile][k step][lane] = A[16 tile + (lane & 15)][4 step + (lane >> 4)], zero beyond the matrix, so that one
   // wave-wide operand load is 512 contiguous bytes
-  double *pF, *pFt, *pS0, *pS0t, *pHS, *pMinv, *pMS;
+  double *pF, *pFt, *pS0, *pS0t, *pHS, *pMinv;
   // fixed rows
   double *lf, *uf, *zf, *yf, *wf, *tf;
   // x-space vectors [K][C]
@@ -29,7 +29,7 @@ struct QpDev {
   int *w_k, *w_i, *w_j;
   double *w_eta, *w_l, *zc, *yc;
   // scalars
-  double* scal;   // SL_COUNT
+  double* scal;   // SL_COUNT, followed by SCP_PART_CAP partial sums of a termination check
   double* part;   // 2 * SCP_PART_CAP
   double* hpf;    // [K][C]: H_f p of the fused PCG
   double* fx;     // [Rf][C]: F x carried by the single-step pipeline (F p goes to tf)
@@ -56,27 +56,28 @@ struct scp_qp {
   bool csr_valid;  // incidence lists match the working set
   bool qx_fresh;   // the current S0 x buffer and the F x slab are exact for x (written by the fused residual kernel)
   int qx_sel;      // which half of HQ holds S0 x (the single-step pipeline ping-pongs: 0 -> rows [K, 2K), 1 -> [0, K))
-  double* h_part;  // pinned, SCP_PART_CAP doubles: per-workgroup partial sums read back at a termination check
   double rho;
   QpDev d;
-  double* h_scal;  // pinned
+  double* h_scal;  // pinned, SL_COUNT + SCP_PART_CAP
 };
 
 
 // scp_qp_fused.hip: one ADMM iteration with the column-local chains fused into column-block kernels
 // (K <= SCP_FUSED_MAX_K).  Same arithmetic as admm_iteration() in scp_qp.hip.
+constexpr int SCP_INV_LDS_MAX_K = 96;  // [H_f | I] (K x 2K doubles) resident in LDS for the Gauss-Jordan inverse
 constexpr int SCP_FUSED_MAX_K = 120;  // (6K + 4K-1) * 128 B of LDS tiles <= 160 KiB (limit raised above 64 KiB)
 constexpr int SCP_PART_CAP = 4096;  // capacity of each partial-sum array (column blocks of the fused path)
 int scp_qp_fused_iteration(scp_qp* qp, int* cg_count);
 // single-PCG-step pipeline (cg_iters == 1 and a non-empty working set): 4 launches per ADMM step
-int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count);
+int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count, bool emit_dy);
 // Deterministic A_W^T g into the G slab (valid incidence lists required): mode 0: g = rho_c zc - yc, 1: g = yc,
 // 2: g = vec[n].  Two launches, no atomics.
 int scp_qp_csr_scatter(scp_qp* qp, int mode, const double* vec);
 int scp_qp_csr_build(scp_qp* qp);
-// (re)pack F, Ft, S0, S0t, HS, Minv, MS into the MFMA operand order; called at the end of build_kkt
+// (re)pack F, Ft, S0, S0t, HS, Minv into the MFMA operand order; called at the end of build_kkt
 int scp_qp_pack_operands(scp_qp* qp);
 static inline size_t scp_packed_count(int R, int M) { return (size_t)((R + 15) / 16) * ((M + 3) / 4) * 64; }
 // Termination-check quantities of the single-step pipeline in 3 launches (row values, column blocks, rows):
 // fills qp->h_scal[SL_RP .. SL_SUPP] like residuals() in scp_qp.hip and leaves S0 x and F x in their slabs.  Synchronises.
-int scp_qp_fused_residuals(scp_qp* qp, bool with_dy);
+// with_dy: 0 none, 1 dyf / dyc hold a snapshot of y taken before the iteration, 2 they hold delta-y already.
+int scp_qp_fused_residuals(scp_qp* qp, int with_dy);

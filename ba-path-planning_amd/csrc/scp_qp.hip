@@ -344,31 +344,35 @@ __global__ __launch_bounds__(256) void build_hf_kernel(int K, double rho, double
   aug[(int64_t)a * 2 * K + K + b] = a == b ? 1.0 : 0.0;
 }
 
-// Gauss-Jordan inverse with [Hf | I] resident in LDS (K <= SCP_INV_LDS_MAX_K); same operations as the global one
+// Gauss-Jordan inverse with [Hf | I] resident in LDS (K <= SCP_INV_LDS_MAX_K); same operations as the global one.
+// Thread (ty, tx): column tx of the augmented matrix, rows ty, ty + TY, ... (no integer divisions in the pivot loop).
 __global__ __launch_bounds__(1024) void spd_inverse_lds_kernel(int K, const double* __restrict__ Hf, double* __restrict__ Minv) {
   extern __shared__ double sh[];  // aug[K][2K] | prow[2K] | col[K]
   const int W = 2 * K;
   double* aug = sh;
   double* prow = aug + K * W;
   double* col = prow + W;
-  for (int e = threadIdx.x; e < K * W; e += blockDim.x) {
-    const int r = e / W, c = e % W;
-    aug[e] = c < K ? Hf[r * K + c] : (c - K == r ? 1.0 : 0.0);
-  }
+  const int TX = W <= 128 ? 128 : 256, TY = 1024 / TX;
+  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x / TX;
+  if (tx < W)
+    for (int r = ty; r < K; r += TY) aug[r * W + tx] = tx < K ? Hf[r * K + tx] : (tx - K == r ? 1.0 : 0.0);
   __syncthreads();
   for (int p = 0; p < K; ++p) {
     const double piv = aug[p * W + p];
-    for (int c = threadIdx.x; c < W; c += blockDim.x) prow[c] = aug[p * W + c] / piv;
-    for (int r = threadIdx.x; r < K; r += blockDim.x) col[r] = aug[r * W + p];
+    if (threadIdx.x < W) prow[threadIdx.x] = aug[p * W + threadIdx.x] / piv;
+    else if (threadIdx.x >= 512 && threadIdx.x - 512 < K) col[threadIdx.x - 512] = aug[(threadIdx.x - 512) * W + p];
     __syncthreads();
-    for (int e = threadIdx.x; e < K * W; e += blockDim.x) {
-      const int r = e / W, c = e % W;
-      if (r == p) aug[e] = prow[c];
-      else aug[e] -= col[r] * prow[c];
+    if (tx < W) {
+      const double pr = prow[tx];
+      for (int r = ty; r < K; r += TY) {
+        if (r == p) aug[r * W + tx] = pr;
+        else aug[r * W + tx] -= col[r] * pr;
+      }
     }
     __syncthreads();
   }
-  for (int e = threadIdx.x; e < K * K; e += blockDim.x) Minv[e] = aug[(e / K) * W + K + (e % K)];
+  if (tx < K)
+    for (int r = ty; r < K; r += TY) Minv[r * K + tx] = aug[r * W + K + tx];
 }
 
 // Gauss-Jordan inverse of the SPD matrix held in aug = [Hf | I] (K x 2K, global memory, one workgroup).
@@ -490,7 +494,7 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.w_l = c.take<double>((size_t)cap);
   d.zc = c.take<double>((size_t)cap);
   d.yc = c.take<double>((size_t)cap);
-  d.scal = c.take<double>(SL_COUNT + SCP_PART_CAP);
+  d.scal = c.take<double>(SL_COUNT + SCP_RESID_CAP);
   d.part = c.take<double>(2 * SCP_PART_CAP);
   d.hpf = c.take<double>(nx);
   d.fx = c.take<double>(nf);
@@ -502,6 +506,7 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.ent_code = c.take<int>((size_t)2 * cap);
   d.coef = c.take<double>((size_t)2 * cap * D);
   d.gval = c.take<double>((size_t)2 * cap);
+  d.gval2 = c.take<double>((size_t)2 * cap);
   d.pos_i = c.take<int>((size_t)cap);
   d.pos_j = c.take<int>((size_t)cap);
   return c.off;
@@ -760,7 +765,7 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
   qp->qx_sel = 0;
   qp->rho = s->rho;
   carve(qp->d, workspace, K, qp->C, row_capacity, D);
-  if (hipHostMalloc(&qp->h_scal, (SL_COUNT + SCP_PART_CAP) * sizeof(double)) != hipSuccess) {
+  if (hipHostMalloc(&qp->h_scal, (SL_COUNT + SCP_RESID_CAP) * sizeof(double)) != hipSuccess) {
     delete qp;
     return scp_fail(ctx, SCP_ERR_HIP, "qp_create: hipHostMalloc failed");
   }
@@ -906,7 +911,7 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
     else if (fused) QP_CHECK(scp_qp_fused_iteration(qp, &cg_total));
     else QP_CHECK(admm_iteration(qp, &cg_total));
     if (will_check) {
-      if (cg1_it) QP_CHECK(scp_qp_fused_residuals(qp, with_dy ? 2 : 0));
+      if (cg1_it) QP_CHECK(scp_qp_fused_residuals(qp, with_dy));
       else QP_CHECK(residuals(qp, with_dy));
       qp->cg1_ready = false;  // the check used gval / G and the Q slabs as scratch; rho may change below
       const double* hs = qp->h_scal;
@@ -921,7 +926,7 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
       if (with_dy) {  // OSQP's is_primal_infeasible on the unscaled problem
         const double ndy = hs[SL_NDY], supp = hs[SL_SUPP];
         if (ndy > st.eps_prim_inf && supp < -st.eps_prim_inf * ndy) {
-          QP_CHECK(certificate_atdy(qp));
+          if (!cg1_it) QP_CHECK(certificate_atdy(qp));  // the fused check has |A^T dy| already
           if (qp->h_scal[SL_NATDY] < st.eps_prim_inf * ndy) {
             info->status_val = -3;
             break;

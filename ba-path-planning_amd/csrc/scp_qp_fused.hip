@@ -508,6 +508,16 @@ __device__ inline double wave_incl_sum(double v) {
   v += dpp_mov0<0x143, 0xC>(v);
   return v;
 }
+// maximum of non-negative values over the 64 lanes, valid in lane 63
+__device__ inline double wave_max_nn(double v) {
+  v = fmax(v, dpp_mov0<0x111, 0xF>(v));
+  v = fmax(v, dpp_mov0<0x112, 0xF>(v));
+  v = fmax(v, dpp_mov0<0x114, 0xF>(v));
+  v = fmax(v, dpp_mov0<0x118, 0xF>(v));
+  v = fmax(v, dpp_mov0<0x142, 0xA>(v));
+  v = fmax(v, dpp_mov0<0x143, 0xC>(v));
+  return v;
+}
 __device__ inline double lane_below(double v) { return dpp_mov0<0x138, 0xF>(v); }  // wave_shr:1 (lane 0 <- 0)
 __device__ inline double lane_above(double v) { return dpp_mov0<0x130, 0xF>(v); }  // wave_shl:1 (lane 63 <- 0)
 
@@ -707,9 +717,8 @@ __global__ __launch_bounds__(FT) void cg1_col_kernel(int K, int Rf, int64_t C, d
         Wc[3 * K - 1 + k] = hh * (c2[e] + 0.5 * c1[e]);
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) rz += __shfl_xor(rz, o);
-    if (lane == 0) s_rz[wave] = rz;
+    rz = wave_incl_sum(rz);
+    if (lane == 63) s_rz[wave] = rz;
   }
   __syncthreads();
   PHASE_MARK(4);
@@ -746,9 +755,8 @@ __global__ __launch_bounds__(256) void cg1_rows_sq_kernel(int64_t nW, int64_t C,
     for (int d = 0; d < D; ++d) ax += weta[n * D + d] * (Qp[bi + d] - Qp[bj + d]);
     acc += ax * ax;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+  acc = wave_incl_sum(acc);
+  if ((threadIdx.x & 63) == 63) sw[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) part_sq[blockIdx.x] = rho * ((sw[0] + sw[1]) + (sw[2] + sw[3]));
 }
@@ -760,12 +768,9 @@ __device__ inline double step_length_256(const double* __restrict__ part_rz, int
   double v = 0.0, q = 0.0;
   for (int b = threadIdx.x; b < nblk; b += 256) v += part_rz[b];
   for (int b = threadIdx.x; b < SQ_BLOCKS; b += 256) q += part_sq[b];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    v += __shfl_xor(v, o);
-    q += __shfl_xor(q, o);
-  }
-  if ((threadIdx.x & 63) == 0) {
+  v = wave_incl_sum(v);  // DPP: totals in lane 63 (an LDS-routed __shfl butterfly costs ten times as much)
+  q = wave_incl_sum(q);
+  if ((threadIdx.x & 63) == 63) {
     sw[0][threadIdx.x >> 6] = v;
     sw[1][threadIdx.x >> 6] = q;
   }
@@ -1180,11 +1185,15 @@ __global__ __launch_bounds__(256) void csr_finish_kernel(int64_t nent, int D, co
 __global__ __launch_bounds__(256) void csr_rowval_kernel(int64_t nW, int mode, double rho, const double* __restrict__ zc,
                                                           const double* __restrict__ yc, const double* __restrict__ vec,
                                                           const int* __restrict__ pos_i, const int* __restrict__ pos_j,
-                                                          double* __restrict__ gval, double* __restrict__ zero,
-                                                          int nzero) {
+                                                          double* __restrict__ gval, const double* __restrict__ vec2,
+                                                          double* __restrict__ gval2) {
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n < nzero) zero[n] = 0.0;  // reduction slots of the launch that follows
   if (n >= nW) return;
+  if (gval2) {  // a second row vector for the same gather
+    const double g2 = vec2[n];
+    gval2[pos_i[n]] = g2;
+    gval2[pos_j[n]] = g2;
+  }
   const double g = mode == 0 ? rho * zc[n] - yc[n] : (mode == 1 ? yc[n] : vec[n]);
   gval[pos_i[n]] = g;
   gval[pos_j[n]] = g;
@@ -1233,7 +1242,7 @@ int scp_qp_csr_scatter(scp_qp* qp, int mode, const double* vec) {
   hipStream_t s = qp->ctx->stream;
   const int64_t nx = (int64_t)qp->K * qp->C;
   hipLaunchKernelGGL(csr_rowval_kernel, dim3((unsigned)((qp->nW + 255) / 256)), dim3(256), 0, s, qp->nW, mode,
-                     qp->rho * qp->st.rho_col_scale, d.zc, d.yc, vec, d.pos_i, d.pos_j, d.gval, (double*)nullptr, 0);
+                     qp->rho * qp->st.rho_col_scale, d.zc, d.yc, vec, d.pos_i, d.pos_j, d.gval, (const double*)nullptr, (double*)nullptr);
   hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, s, qp->K, qp->N, qp->D,
                      d.cell_ptr, d.coef, d.gval, d.G);
   FUSED_LAUNCHED(qp);
@@ -1305,24 +1314,58 @@ __device__ inline void atomic_max_nn(double* addr, double v) {
   atomicMax((unsigned long long*)addr, (unsigned long long)__double_as_longlong(v));
 }
 
+// per-workgroup partial results of a check: [rp, |Ax|, |z|, rd, |Px|, |A^T y|, |dy|, supp, |A^T dy|] (maxima / a sum),
+// reduced on the host -- 7 same-address atomics per workgroup cost more than the rest of the kernel
+constexpr int RS_RP = 0, RS_NAX = 1, RS_NZ = 2, RS_RD = 3, RS_NPX = 4, RS_NATY = 5, RS_NDY = 6, RS_SUPP = 7, RS_NATDY = 8;
+
+// A^T v for one column (one wave), v = (v_f in Vc[0, Rf), v_c gathered in Gc[0, K)), time steps in DESCENDING order
+// (k = KM - i): reverse cumulative sums as ascending scans.  Returns the value for step k of index (lane, e).
+template <int E>
+__device__ inline void column_At(int K, double h, const double* Vc, const double* Gc, double (&out)[E]) {
+  const int lane = threadIdx.x & 63, KM = 64 * E - 1;
+  const double hh = h * h;
+  double yj[E], ya[E], u1[E], u2[E], g[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int k = KM - (lane * E + e);
+    const bool ok = k < K;
+    yj[e] = k < K - 1 ? Vc[k] : 0.0;
+    ya[e] = ok ? Vc[K - 1 + k] : 0.0;
+    const double yv = ok ? Vc[2 * K - 1 + k] : 0.0;
+    const double yp = ok ? Vc[3 * K - 1 + k] : 0.0;
+    g[e] = ok ? Gc[k] : 0.0;
+    u1[e] = h * yv + 0.5 * hh * (yp - g[e]);
+    u2[e] = yp + g[e];
+  }
+  double d1[E], d2[E], s1[E], s2[E], yjp[E];
+  wave_scan<E>(u1, d1, s1);
+  wave_scan<E>(u2, s1, s2);
+  wave_scan<E>(s1, s2, d2);
+  wave_next<E>(yj, yjp);
+#pragma unroll
+  for (int e = 0; e < E; ++e) out[e] = ((yjp[e] - yj[e]) / h + ya[e]) + (d1[e] + 0.5 * hh * g[e]) + hh * d2[e];
+}
+
 // Column part of the check, with the integrator blocks as wave scans like cg1_col_kernel (one wave per column):
-//   F x, S0 x (stored: the pipeline's carried slabs are refreshed exactly), A^T y = F^T y_f + S0^T G(yc), and the
-//   maxima of the primal / dual residuals and of delta-y over this block's 16 columns.
+//   F x, S0 x (stored: the pipeline's carried slabs are refreshed exactly), A^T y = F^T y_f + S0^T G(yc), the maxima of
+//   the primal / dual residuals over this block's 16 columns and, with_dy (dyf / gval2 hold delta-y of the last
+//   iteration), |dy|, its support value and |A^T dy| of OSQP's primal infeasibility certificate.
 template <int E>
 __global__ __launch_bounds__(FT) void cg1_resid_col_kernel(int K, int Rf, int64_t C, double h, int N, int D, int with_dy,
                                                             const double* __restrict__ x, const double* __restrict__ zf,
                                                             const double* __restrict__ yf, const double* __restrict__ lf,
-                                                            const double* __restrict__ uf, double* __restrict__ dyf,
+                                                            const double* __restrict__ uf, const double* __restrict__ dyf,
                                                             const int* __restrict__ cell_ptr,
                                                             const double* __restrict__ coef,
-                                                            const double* __restrict__ gval, double* __restrict__ Qx,
-                                                            double* __restrict__ Fx, double* __restrict__ scal,
-                                                            double* __restrict__ part_supp) {
+                                                            const double* __restrict__ gval,
+                                                            const double* __restrict__ gval2, double* __restrict__ Qx,
+                                                            double* __restrict__ Fx, double* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int RSF = pad_col(Rf), RSK = pad_col(K);
-  double* YF = lds;              // [16][RSF]  y_f, then F x (each column is read and rewritten by its own wave)
+  double* YF = lds;              // [16][RSF]  y_f, then delta-y_f, then F x (a column is only touched by its own wave)
   double* Gx = YF + CB * RSF;    // [16][RSK]  gather of eta * yc
-  double* Xt = Gx + CB * RSK;    // [16][RSK]  x
+  double* G2 = Gx + CB * RSK;    // [16][RSK]  gather of eta * delta-yc
+  double* Xt = G2 + CB * RSK;    // [16][RSK]  x
   double* Qt = Xt + CB * RSK;    // [16][RSK]  S0 x
   const int64_t c0 = (int64_t)blockIdx.x * CB;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1330,69 +1373,66 @@ __global__ __launch_bounds__(FT) void cg1_resid_col_kernel(int K, int Rf, int64_
   const bool cok = c0 + c < C;
   const int col = (int)(c0 + c), agent = col / D, dd_ = col - agent * D;
   const double hh = h * h;
-  double ndy = 0.0, supp = 0.0;
+  double ndy = 0.0, supp = 0.0, natdy = 0.0;
+  PHASE_MARK(32);
   for (int k = kg; k < K; k += FT / CB) {
-    double acc = 0.0, xv = 0.0;
+    double acc = 0.0, acc2 = 0.0, xv = 0.0;
     if (cok) {
       const int cell = k * N + agent;
-      const int t1 = cell_ptr[cell + 1];
-      for (int t = cell_ptr[cell]; t < t1; ++t) acc += coef[(size_t)t * D + dd_] * gval[t];
+      const int t0 = cell_ptr[cell], t1 = cell_ptr[cell + 1];
+      for (int t = t0; t < t1; ++t) acc += coef[(size_t)t * D + dd_] * gval[t];
+      if (with_dy)
+        for (int t = t0; t < t1; ++t) acc2 += coef[(size_t)t * D + dd_] * gval2[t];
       xv = x[(int64_t)k * C + c0 + c];
     }
     Gx[c * RSK + k] = acc;
+    G2[c * RSK + k] = acc2;
     Xt[c * RSK + k] = xv;
   }
-  for (int r = kg; r < Rf; r += FT / CB) {
-    double y = 0.0;
-    if (cok) {
-      const int64_t g = (int64_t)r * C + c0 + c;
-      y = yf[g];
-      if (with_dy) {
-        const double dd = with_dy == 2 ? dyf[g] : y - dyf[g];  // 2: the update kernel stored delta-y
-        if (with_dy == 1) dyf[g] = dd;
+  for (int r = kg; r < Rf; r += FT / CB) YF[c * RSF + r] = cok ? yf[(int64_t)r * C + c0 + c] : 0.0;
+  __syncthreads();
+  PHASE_MARK(33);
+  double rd = 0.0, npx = 0.0, nat = 0.0;
+  {
+    double aty[E];
+    column_At<E>(K, h, YF + wave * RSF, Gx + wave * RSK, aty);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int k = (64 * E - 1) - (lane * E + e);
+      if (k < K) {
+        const double px = 2.0 * Xt[wave * RSK + k];
+        rd = fmax(rd, fabs(px + aty[e]));
+        npx = fmax(npx, fabs(px));
+        nat = fmax(nat, fabs(aty[e]));
+      }
+    }
+  }
+  PHASE_MARK(34);
+  if (with_dy) {  // wave-uniform
+    __syncthreads();
+    for (int r = kg; r < Rf; r += FT / CB) {
+      double dd = 0.0;
+      if (cok) {
+        const int64_t g = (int64_t)r * C + c0 + c;
+        dd = dyf[g];
         ndy = fmax(ndy, fabs(dd));
         supp += uf[g] * fmax(dd, 0.0) + lf[g] * fmin(dd, 0.0);
       }
+      YF[c * RSF + r] = dd;
     }
-    YF[c * RSF + r] = y;
+    __syncthreads();
+    double atdy[E];
+    column_At<E>(K, h, YF + wave * RSF, G2 + wave * RSK, atdy);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int k = (64 * E - 1) - (lane * E + e);
+      if (k < K) natdy = fmax(natdy, fabs(atdy[e]));
+    }
   }
-  __syncthreads();
-  double rd = 0.0, npx = 0.0, nat = 0.0;
+  PHASE_MARK(35);
   {
+    // F x and S0 x in ascending order (every lane of this wave is done with its column of YF)
     double* Yc = YF + wave * RSF;
-    // A^T y over the time steps in descending order (reverse cumulative sums as ascending scans)
-    const int KM = 64 * E - 1;
-    double yj[E], ya[E], u1[E], u2[E], g[E], xk[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const int k = KM - (lane * E + e);
-      const bool ok = k < K;
-      yj[e] = k < K - 1 ? Yc[k] : 0.0;
-      ya[e] = ok ? Yc[K - 1 + k] : 0.0;
-      const double yv = ok ? Yc[2 * K - 1 + k] : 0.0;
-      const double yp = ok ? Yc[3 * K - 1 + k] : 0.0;
-      g[e] = ok ? Gx[wave * RSK + k] : 0.0;
-      xk[e] = ok ? Xt[wave * RSK + k] : 0.0;
-      u1[e] = h * yv + 0.5 * hh * (yp - g[e]);
-      u2[e] = yp + g[e];
-    }
-    double d1[E], d2[E], s1[E], s2[E], yjp[E];
-    wave_scan<E>(u1, d1, s1);
-    wave_scan<E>(u2, s1, s2);
-    wave_scan<E>(s1, s2, d2);
-    wave_next<E>(yj, yjp);
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const int k = KM - (lane * E + e);
-      if (k < K) {
-        const double aty = ((yjp[e] - yj[e]) / h + ya[e]) + (d1[e] + 0.5 * hh * g[e]) + hh * d2[e];
-        const double px = 2.0 * xk[e];
-        rd = fmax(rd, fabs(px + aty));
-        npx = fmax(npx, fabs(px));
-        nat = fmax(nat, fabs(aty));
-      }
-    }
-    // F x and S0 x in ascending order (every lane of this wave has read its y_f entries above)
     double pk[E], c1[E], c2[E], t1[E], t2[E], c1p[E], pn[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -1416,6 +1456,7 @@ __global__ __launch_bounds__(FT) void cg1_resid_col_kernel(int K, int Rf, int64_
     }
   }
   __syncthreads();
+  PHASE_MARK(36);
   double rp = 0.0, nax = 0.0, nz = 0.0;
   if (cok) {
     for (int r = kg; r < Rf; r += FT / CB) {
@@ -1428,16 +1469,25 @@ __global__ __launch_bounds__(FT) void cg1_resid_col_kernel(int K, int Rf, int64_
     }
     for (int k = kg; k < K; k += FT / CB) Qx[(int64_t)k * C + c0 + c] = Qt[c * RSK + k];
   }
-  rp = wg_max(rp); nax = wg_max(nax); nz = wg_max(nz);
-  rd = wg_max(rd); npx = wg_max(npx); nat = wg_max(nat);
-  ndy = wg_max(ndy);
-  supp = wg_sum(supp);
-  if (threadIdx.x == 0) {
-    atomic_max_nn(scal + SL_RP, rp); atomic_max_nn(scal + SL_NAX, nax); atomic_max_nn(scal + SL_NZ, nz);
-    atomic_max_nn(scal + SL_RD, rd); atomic_max_nn(scal + SL_NPX, npx); atomic_max_nn(scal + SL_NATY, nat);
-    atomic_max_nn(scal + SL_NDY, ndy);
-    part_supp[blockIdx.x] = supp;  // summed on the host in block order: deterministic
+  PHASE_MARK(37);
+  // nine workgroup reductions with one barrier: DPP inside the waves, lane 63 of every wave to LDS, 9 threads finish
+  __shared__ double red[NWV][9];
+  {
+    const double v[9] = {wave_max_nn(rp),  wave_max_nn(nax), wave_max_nn(nz),     wave_max_nn(rd),   wave_max_nn(npx),
+                         wave_max_nn(nat), wave_max_nn(ndy), wave_incl_sum(supp), wave_max_nn(natdy)};
+    if (lane == 63) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) red[wave][j] = v[j];
+    }
   }
+  __syncthreads();
+  if (threadIdx.x < 9) {
+    const int j = threadIdx.x;
+    double t = 0.0;
+    for (int w = 0; w < NWV; ++w) t = j == RS_SUPP ? t + red[w][j] : fmax(t, red[w][j]);
+    part[(size_t)blockIdx.x * SCP_RESID_STRIDE + j] = t;
+  }
+  PHASE_MARK(38);
 }
 
 constexpr int RESID_ROW_BLOCKS = 128;
@@ -1447,9 +1497,8 @@ __global__ __launch_bounds__(256) void cg1_resid_rows_kernel(int64_t nW, int64_t
                                                               const int* __restrict__ wi, const int* __restrict__ wj,
                                                               const double* __restrict__ weta,
                                                               const double* __restrict__ wl, const double* __restrict__ Qx,
-                                                              const double* __restrict__ zc, const double* __restrict__ yc,
-                                                              double* __restrict__ dyc, double* __restrict__ scal,
-                                                              double* __restrict__ part_supp) {
+                                                              const double* __restrict__ zc,
+                                                              const double* __restrict__ dyc, double* __restrict__ part) {
   __shared__ double sm[4][5];
   double rp = 0.0, nax = 0.0, nz = 0.0, ndy = 0.0, supp = 0.0;
   for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nW; n += (int64_t)RESID_ROW_BLOCKS * 256) {
@@ -1463,8 +1512,7 @@ __global__ __launch_bounds__(256) void cg1_resid_rows_kernel(int64_t nW, int64_t
     nax = fmax(nax, fabs(a));
     nz = fmax(nz, fabs(z));
     if (with_dy) {
-      const double dd = with_dy == 2 ? dyc[n] : fmin(yc[n] - dyc[n], 0.0);  // u = +inf: polar of the recession cone
-      if (with_dy == 1) dyc[n] = dd;
+      const double dd = dyc[n];  // delta-y of the last iteration, already projected (u = +inf)
       ndy = fmax(ndy, fabs(dd));
       supp += wl[n] * dd;
     }
@@ -1478,17 +1526,19 @@ __global__ __launch_bounds__(256) void cg1_resid_rows_kernel(int64_t nW, int64_t
   if ((threadIdx.x & 63) == 0) { sm[w][0] = rp; sm[w][1] = nax; sm[w][2] = nz; sm[w][3] = ndy; sm[w][4] = supp; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomic_max_nn(scal + SL_RP, fmax(fmax(sm[0][0], sm[1][0]), fmax(sm[2][0], sm[3][0])));
-    atomic_max_nn(scal + SL_NAX, fmax(fmax(sm[0][1], sm[1][1]), fmax(sm[2][1], sm[3][1])));
-    atomic_max_nn(scal + SL_NZ, fmax(fmax(sm[0][2], sm[1][2]), fmax(sm[2][2], sm[3][2])));
-    atomic_max_nn(scal + SL_NDY, fmax(fmax(sm[0][3], sm[1][3]), fmax(sm[2][3], sm[3][3])));
-    part_supp[blockIdx.x] = (sm[0][4] + sm[1][4]) + (sm[2][4] + sm[3][4]);
+    double* o = part + (size_t)blockIdx.x * SCP_RESID_STRIDE;
+    o[RS_RP] = fmax(fmax(sm[0][0], sm[1][0]), fmax(sm[2][0], sm[3][0]));
+    o[RS_NAX] = fmax(fmax(sm[0][1], sm[1][1]), fmax(sm[2][1], sm[3][1]));
+    o[RS_NZ] = fmax(fmax(sm[0][2], sm[1][2]), fmax(sm[2][2], sm[3][2]));
+    o[RS_RD] = o[RS_NPX] = o[RS_NATY] = o[RS_NATDY] = 0.0;
+    o[RS_NDY] = fmax(fmax(sm[0][3], sm[1][3]), fmax(sm[2][3], sm[3][3]));
+    o[RS_SUPP] = (sm[0][4] + sm[1][4]) + (sm[2][4] + sm[3][4]);
   }
 }
 
 }  // namespace
 
-int scp_qp_fused_residuals(scp_qp* qp, int with_dy) {
+int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
   const QpDev& d = qp->d;
   scp_ctx* ctx = qp->ctx;
   hipStream_t s = ctx->stream;
@@ -1496,36 +1546,44 @@ int scp_qp_fused_residuals(scp_qp* qp, int with_dy) {
   const int64_t C = qp->C, nx = (int64_t)K * C;
   const int nblk = (int)((C + CB - 1) / CB);
   double* Qx = qp->qx_sel ? d.HQ : d.HQ + nx;
-  double* part = d.scal + SL_COUNT;  // [0, nblk): column blocks, [nblk, nblk + RESID_ROW_BLOCKS): row blocks
-  // gval = yc and the maxima slots zeroed (one launch)
+  double* part = d.scal + SL_COUNT;  // [nblk column blocks | RESID_ROW_BLOCKS row blocks][SCP_RESID_STRIDE]
   hipLaunchKernelGGL(csr_rowval_kernel, dim3((unsigned)((qp->nW + 255) / 256)), dim3(256), 0, s, qp->nW, 1, 0.0, d.zc,
-                     d.yc, (const double*)nullptr, d.pos_i, d.pos_j, d.gval, d.scal + SL_RP, 9);
-  const size_t lds = (size_t)CB * (pad_col(Rf) + 3 * pad_col(K)) * sizeof(double);
+                     d.yc, (const double*)nullptr, d.pos_i, d.pos_j, d.gval, with_dy ? d.dyc : (const double*)nullptr,
+                     with_dy ? d.gval2 : (double*)nullptr);
+  const size_t lds = (size_t)CB * (pad_col(Rf) + 4 * pad_col(K)) * sizeof(double);
   if (K <= 64) {
     int rc = allow_lds(qp, cg1_resid_col_kernel<1>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(cg1_resid_col_kernel<1>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->h, qp->N, qp->D, with_dy, d.x,
-                       d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval, Qx, d.fx, d.scal, part);
+    hipLaunchKernelGGL(cg1_resid_col_kernel<1>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->h, qp->N, qp->D, with_dy ? 1 : 0,
+                       d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval, d.gval2, Qx, d.fx, part);
   } else {
     int rc = allow_lds(qp, cg1_resid_col_kernel<2>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(cg1_resid_col_kernel<2>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->h, qp->N, qp->D, with_dy, d.x,
-                       d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval, Qx, d.fx, d.scal, part);
+    hipLaunchKernelGGL(cg1_resid_col_kernel<2>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->h, qp->N, qp->D, with_dy ? 1 : 0,
+                       d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval, d.gval2, Qx, d.fx, part);
   }
+  double* rpart = part + (size_t)nblk * SCP_RESID_STRIDE;
   if (qp->D == 2)
-    hipLaunchKernelGGL(cg1_resid_rows_kernel<2>, dim3(RESID_ROW_BLOCKS), dim3(256), 0, s, qp->nW, C, with_dy, d.w_k,
-                       d.w_i, d.w_j, d.w_eta, d.w_l, Qx, d.zc, d.yc, d.dyc, d.scal, part + nblk);
+    hipLaunchKernelGGL(cg1_resid_rows_kernel<2>, dim3(RESID_ROW_BLOCKS), dim3(256), 0, s, qp->nW, C, with_dy ? 1 : 0, d.w_k,
+                       d.w_i, d.w_j, d.w_eta, d.w_l, Qx, d.zc, d.dyc, rpart);
   else
-    hipLaunchKernelGGL(cg1_resid_rows_kernel<3>, dim3(RESID_ROW_BLOCKS), dim3(256), 0, s, qp->nW, C, with_dy, d.w_k,
-                       d.w_i, d.w_j, d.w_eta, d.w_l, Qx, d.zc, d.yc, d.dyc, d.scal, part + nblk);
+    hipLaunchKernelGGL(cg1_resid_rows_kernel<3>, dim3(RESID_ROW_BLOCKS), dim3(256), 0, s, qp->nW, C, with_dy ? 1 : 0, d.w_k,
+                       d.w_i, d.w_j, d.w_eta, d.w_l, Qx, d.zc, d.dyc, rpart);
   FUSED_LAUNCHED(qp);
-  const int npart = nblk + RESID_ROW_BLOCKS;  // partials follow the scalar slots: one copy
-  SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->h_scal, d.scal, (size_t)(SL_COUNT + npart) * sizeof(double), hipMemcpyDeviceToHost, s));
+  const int npart = nblk + RESID_ROW_BLOCKS;
+  SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->h_scal + SL_COUNT, part, (size_t)npart * SCP_RESID_STRIDE * sizeof(double),
+                                    hipMemcpyDeviceToHost, s));
   SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));
-  double supp = 0.0;
-  if (with_dy)
-    for (int b = 0; b < npart; ++b) supp += qp->h_scal[SL_COUNT + b];
-  qp->h_scal[SL_SUPP] = supp;
+  double* hs = qp->h_scal;
+  static const int slot[9] = {SL_RP, SL_NAX, SL_NZ, SL_RD, SL_NPX, SL_NATY, SL_NDY, SL_SUPP, SL_NATDY};
+  for (int j = 0; j < 9; ++j) hs[slot[j]] = 0.0;
+  for (int b = 0; b < npart; ++b) {  // fixed order: deterministic
+    const double* o = hs + SL_COUNT + (size_t)b * SCP_RESID_STRIDE;
+    for (int j = 0; j < 9; ++j) {
+      if (j == RS_SUPP) hs[SL_SUPP] += o[j];
+      else hs[slot[j]] = fmax(hs[slot[j]], o[j]);
+    }
+  }
   qp->qx_fresh = true;
   return SCP_OK;
 }

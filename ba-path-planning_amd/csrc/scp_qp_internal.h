@@ -29,7 +29,7 @@ struct QpDev {
   int *w_k, *w_i, *w_j;
   double *w_eta, *w_l, *zc, *yc;
   // scalars
-  double* scal;   // SL_COUNT, followed by SCP_PART_CAP partial sums of a termination check
+  double* scal;   // SL_COUNT, followed by SCP_RESID_CAP partial results of a termination check
   double* part;   // 2 * SCP_PART_CAP
   double* hpf;    // [K][C]: H_f p of the fused PCG
   double* fx;     // [Rf][C]: F x carried by the single-step pipeline (F p goes to tf)
@@ -41,6 +41,7 @@ struct QpDev {
   int* ent_code;  // [2 cap]   2 n + side, sorted inside every cell (side 0: agent i, +eta; side 1: agent j, -eta)
   double* coef;   // [2 cap][D] signed eta of the entry
   double* gval;   // [2 cap]   per-entry row value, written by the row kernels (no atomics)
+  double* gval2;  // [2 cap]   second row vector of a termination check (delta-y)
   int *pos_i, *pos_j;  // [cap] entry positions of row n
 };
 
@@ -58,12 +59,14 @@ struct scp_qp {
   int qx_sel;      // which half of HQ holds S0 x (the single-step pipeline ping-pongs: 0 -> rows [K, 2K), 1 -> [0, K))
   double rho;
   QpDev d;
-  double* h_scal;  // pinned, SL_COUNT + SCP_PART_CAP
+  double* h_scal;  // pinned, SL_COUNT + SCP_RESID_CAP
 };
 
 
 // scp_qp_fused.hip: one ADMM iteration with the column-local chains fused into column-block kernels
 // (K <= SCP_FUSED_MAX_K).  Same arithmetic as admm_iteration() in scp_qp.hip.
+constexpr int SCP_RESID_STRIDE = 12;  // doubles per workgroup in the partial results of a fused termination check
+constexpr int SCP_RESID_CAP = (4096 / 2 + 128) * SCP_RESID_STRIDE;  // (SCP_PART_CAP / 2 column blocks + row blocks)
 constexpr int SCP_INV_LDS_MAX_K = 96;  // [H_f | I] (K x 2K doubles) resident in LDS for the Gauss-Jordan inverse
 constexpr int SCP_FUSED_MAX_K = 120;  // (6K + 4K-1) * 128 B of LDS tiles <= 160 KiB (limit raised above 64 KiB)
 constexpr int SCP_PART_CAP = 4096;  // capacity of each partial-sum array (column blocks of the fused path)
@@ -79,5 +82,5 @@ int scp_qp_pack_operands(scp_qp* qp);
 static inline size_t scp_packed_count(int R, int M) { return (size_t)((R + 15) / 16) * ((M + 3) / 4) * 64; }
 // Termination-check quantities of the single-step pipeline in 3 launches (row values, column blocks, rows):
 // fills qp->h_scal[SL_RP .. SL_SUPP] like residuals() in scp_qp.hip and leaves S0 x and F x in their slabs.  Synchronises.
-// with_dy: 0 none, 1 dyf / dyc hold a snapshot of y taken before the iteration, 2 they hold delta-y already.
-int scp_qp_fused_residuals(scp_qp* qp, int with_dy);
+// with_dy: dyf / dyc hold delta-y of the last iteration (cg1_update_kernel); also fills h_scal[SL_NATDY].
+int scp_qp_fused_residuals(scp_qp* qp, bool with_dy);

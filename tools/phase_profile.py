@@ -39,6 +39,12 @@ def main():
     for i, name in enumerate(COLA):
         print(f"  {name:56s} {(t[i + 1] - t[i]) * 0.01:7.2f} us")
     print(f"  {'total inside the workgroup':56s} {(t[5] - t[0]) * 0.01:7.2f} us")
+    names = ["loads x, y_f, gathers", "A^T y (scans)", "delta-y loads, A^T dy", "F x, S0 x (scans)", "epilogue loads / stores",
+             "reductions"]
+    print("cg1_resid_col_kernel, middle workgroup:")
+    for i, name in enumerate(names):
+        print(f"  {name:56s} {(t[33 + i] - t[32 + i]) * 0.01:7.2f} us")
+    print(f"  {'total inside the workgroup':56s} {(t[38] - t[32]) * 0.01:7.2f} us")
 
 
 if __name__ == "__main__":

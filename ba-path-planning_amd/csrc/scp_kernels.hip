@@ -297,23 +297,40 @@ __global__ void pair_stats_init_kernel(scp_pair_stats* s) {
   s->max_violation = -__longlong_as_double(0x7FF0000000000000LL);
 }
 
-__device__ inline double wave_min(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+// Wavefront reductions on DPP moves (row_shr 1, 2, 4, 8, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows
+// 2, 3): result in LANE 63.  Lanes without a source keep their own value (idempotent operators only).  The
+// __shfl_xor butterfly goes through the LDS crossbar and costs about ten times as much.
+template <int CTRL, int ROW_MASK>
+__device__ inline unsigned long long dpp_self_u64(unsigned long long v) {
+  const int lo = (int)(v & 0xFFFFFFFFu), hi = (int)(v >> 32);
+  const unsigned int l2 = (unsigned int)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+  const unsigned int h2 = (unsigned int)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+  return ((unsigned long long)h2 << 32) | l2;
+}
+template <typename Op>
+__device__ inline unsigned long long wave_reduce_u64(unsigned long long v, Op op) {
+  v = op(v, dpp_self_u64<0x111, 0xF>(v));
+  v = op(v, dpp_self_u64<0x112, 0xF>(v));
+  v = op(v, dpp_self_u64<0x114, 0xF>(v));
+  v = op(v, dpp_self_u64<0x118, 0xF>(v));
+  v = op(v, dpp_self_u64<0x142, 0xA>(v));
+  v = op(v, dpp_self_u64<0x143, 0xC>(v));
   return v;
+}
+__device__ inline double wave_min(double v) {
+  return __longlong_as_double((long long)wave_reduce_u64((unsigned long long)__double_as_longlong(v),
+      [](unsigned long long a, unsigned long long b) {
+        return (unsigned long long)__double_as_longlong(fmin(__longlong_as_double((long long)a), __longlong_as_double((long long)b)));
+      }));
 }
 __device__ inline double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  return v;
+  return __longlong_as_double((long long)wave_reduce_u64((unsigned long long)__double_as_longlong(v),
+      [](unsigned long long a, unsigned long long b) {
+        return (unsigned long long)__double_as_longlong(fmax(__longlong_as_double((long long)a), __longlong_as_double((long long)b)));
+      }));
 }
 __device__ inline unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long w = __shfl_xor(v, o);
-    v = w < v ? w : v;
-  }
-  return v;
+  return wave_reduce_u64(v, [](unsigned long long a, unsigned long long b) { return b < a ? b : a; });
 }
 
 // positive doubles compare like their bit patterns
@@ -643,7 +660,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
   } else {
     my_maxv = wave_max(my_maxv);
   }
-  if ((threadIdx.x & 63) == 0) {
+  if ((threadIdx.x & 63) == 63) {
     red_d[threadIdx.x >> 6] = MODE != MODE_VIOLATIONS ? my_min : my_maxv;
     red_u[threadIdx.x >> 6] = my_first;
   }

@@ -507,6 +507,7 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.coef = c.take<double>((size_t)2 * cap * D);
   d.gval = c.take<double>((size_t)2 * cap);
   d.gval2 = c.take<double>((size_t)2 * cap);
+  d.gval3 = c.take<double>((size_t)2 * cap);
   d.pos_i = c.take<int>((size_t)cap);
   d.pos_j = c.take<int>((size_t)cap);
   return c.off;
@@ -765,10 +766,13 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
   qp->qx_sel = 0;
   qp->rho = s->rho;
   carve(qp->d, workspace, K, qp->C, row_capacity, D);
-  if (hipHostMalloc(&qp->h_scal, (SL_COUNT + SCP_RESID_CAP) * sizeof(double)) != hipSuccess) {
+  qp->check_seq = 0;
+  if (hipHostMalloc(&qp->h_scal, (SL_COUNT + SCP_RESID_CAP + 1) * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&qp->h_scal_dev, qp->h_scal, 0) != hipSuccess) {
     delete qp;
     return scp_fail(ctx, SCP_ERR_HIP, "qp_create: hipHostMalloc failed");
   }
+  memset(qp->h_scal, 0, (SL_COUNT + SCP_RESID_CAP + 1) * sizeof(double));  // incl. the completion flag
   // constant blocks (scp.py:10-28, :198-203, :227-232, :489-491), built on the host once per (K, h)
   const int Rf = qp->Rf;
   std::vector<double> F((size_t)Rf * K, 0.0), Ft((size_t)Rf * K, 0.0), S0((size_t)K * K, 0.0), S0t((size_t)K * K, 0.0),
@@ -913,7 +917,8 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
     if (will_check) {
       if (cg1_it) QP_CHECK(scp_qp_fused_residuals(qp, with_dy));
       else QP_CHECK(residuals(qp, with_dy));
-      qp->cg1_ready = false;  // the check used gval / G and the Q slabs as scratch; rho may change below
+      if (!cg1_it) qp->cg1_ready = false;  // residuals() used G and the Q slabs as scratch (the fused check keeps
+                                           // the pipeline's carried state and refreshes S0 x, F x exactly)
       const double* hs = qp->h_scal;
       rp = hs[SL_RP];
       rd = hs[SL_RD];
@@ -944,6 +949,7 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
         nr = std::exp2(std::round(4.0 * std::log2(nr)) / 4.0);
         if (nr > qp->rho * st.adaptive_rho_tolerance || nr < qp->rho / st.adaptive_rho_tolerance) {
           qp->rho = nr;
+          qp->cg1_ready = false;  // the carried row values depend on rho
           QP_CHECK(build_kkt(qp));
           ++info->rho_updates;
         }

@@ -10,6 +10,7 @@
 // An ADMM step with n PCG steps is 4n + 3 launches, 7 at the default n = 1 (15n + ... on the generic path of scp_qp.hip, which stays as the fallback
 // for K > 128 and as the use_mfma = 0/2 reference); the arithmetic is the same, statement by statement.
 #include "scp_qp_internal.h"
+#include <chrono>
 #include <cstdlib>
 
 namespace {
@@ -1538,6 +1539,14 @@ __global__ __launch_bounds__(256) void cg1_resid_rows_kernel(int64_t nW, int64_t
 
 }  // namespace
 
+namespace {
+// last launch of a check: everything before it in the stream has completed and, the partials living in host memory,
+// is visible to the host; the host spins on this word instead of sleeping in hipStreamSynchronize (25 us per check)
+__global__ void check_done_kernel(unsigned long long* flag, unsigned long long seq) {
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
 int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
   const QpDev& d = qp->d;
   scp_ctx* ctx = qp->ctx;
@@ -1546,21 +1555,21 @@ int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
   const int64_t C = qp->C, nx = (int64_t)K * C;
   const int nblk = (int)((C + CB - 1) / CB);
   double* Qx = qp->qx_sel ? d.HQ : d.HQ + nx;
-  double* part = d.scal + SL_COUNT;  // [nblk column blocks | RESID_ROW_BLOCKS row blocks][SCP_RESID_STRIDE]
+  double* part = qp->h_scal_dev + SL_COUNT;  // [nblk column blocks | RESID_ROW_BLOCKS row blocks][SCP_RESID_STRIDE]
   hipLaunchKernelGGL(csr_rowval_kernel, dim3((unsigned)((qp->nW + 255) / 256)), dim3(256), 0, s, qp->nW, 1, 0.0, d.zc,
-                     d.yc, (const double*)nullptr, d.pos_i, d.pos_j, d.gval, with_dy ? d.dyc : (const double*)nullptr,
-                     with_dy ? d.gval2 : (double*)nullptr);
+                     d.yc, (const double*)nullptr, d.pos_i, d.pos_j, d.gval2, with_dy ? d.dyc : (const double*)nullptr,
+                     with_dy ? d.gval3 : (double*)nullptr);
   const size_t lds = (size_t)CB * (pad_col(Rf) + 4 * pad_col(K)) * sizeof(double);
   if (K <= 64) {
     int rc = allow_lds(qp, cg1_resid_col_kernel<1>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(cg1_resid_col_kernel<1>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->h, qp->N, qp->D, with_dy ? 1 : 0,
-                       d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval, d.gval2, Qx, d.fx, part);
+                       d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval2, d.gval3, Qx, d.fx, part);
   } else {
     int rc = allow_lds(qp, cg1_resid_col_kernel<2>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(cg1_resid_col_kernel<2>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->h, qp->N, qp->D, with_dy ? 1 : 0,
-                       d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval, d.gval2, Qx, d.fx, part);
+                       d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval2, d.gval3, Qx, d.fx, part);
   }
   double* rpart = part + (size_t)nblk * SCP_RESID_STRIDE;
   if (qp->D == 2)
@@ -1571,9 +1580,22 @@ int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
                        d.w_i, d.w_j, d.w_eta, d.w_l, Qx, d.zc, d.dyc, rpart);
   FUSED_LAUNCHED(qp);
   const int npart = nblk + RESID_ROW_BLOCKS;
-  SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->h_scal + SL_COUNT, part, (size_t)npart * SCP_RESID_STRIDE * sizeof(double),
-                                    hipMemcpyDeviceToHost, s));
-  SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  volatile unsigned long long* flag = (volatile unsigned long long*)(qp->h_scal + SL_COUNT + SCP_RESID_CAP);
+  const unsigned long long seq = ++qp->check_seq;
+  hipLaunchKernelGGL(check_done_kernel, dim3(1), dim3(1), 0, s, (unsigned long long*)(qp->h_scal_dev + SL_COUNT + SCP_RESID_CAP),
+                     seq);
+  FUSED_LAUNCHED(qp);
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (*flag != seq) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
+    }
+    if (*flag != seq) SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // a fault surfaces here
+    if (*flag != seq) return scp_fail(ctx, SCP_ERR_HIP, "fused check: completion flag not written");
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
   double* hs = qp->h_scal;
   static const int slot[9] = {SL_RP, SL_NAX, SL_NZ, SL_RD, SL_NPX, SL_NATY, SL_NDY, SL_SUPP, SL_NATDY};
   for (int j = 0; j < 9; ++j) hs[slot[j]] = 0.0;

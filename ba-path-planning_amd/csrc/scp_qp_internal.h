@@ -41,7 +41,8 @@ struct QpDev {
   int* ent_code;  // [2 cap]   2 n + side, sorted inside every cell (side 0: agent i, +eta; side 1: agent j, -eta)
   double* coef;   // [2 cap][D] signed eta of the entry
   double* gval;   // [2 cap]   per-entry row value, written by the row kernels (no atomics)
-  double* gval2;  // [2 cap]   second row vector of a termination check (delta-y)
+  double* gval2;  // [2 cap]   row vectors of a termination check: yc ...
+  double* gval3;  // [2 cap]   ... and delta-yc (gval keeps the pipeline's values across a check)
   int *pos_i, *pos_j;  // [cap] entry positions of row n
 };
 
@@ -59,7 +60,9 @@ struct scp_qp {
   int qx_sel;      // which half of HQ holds S0 x (the single-step pipeline ping-pongs: 0 -> rows [K, 2K), 1 -> [0, K))
   double rho;
   QpDev d;
-  double* h_scal;  // pinned, SL_COUNT + SCP_RESID_CAP
+  double* h_scal;  // pinned, SL_COUNT + SCP_RESID_CAP doubles + the completion flag of a fused check
+  double* h_scal_dev;  // the same memory as the device sees it: the check kernels write their partials straight to it
+  unsigned long long check_seq;  // value the flag takes when the current check has finished
 };
 
 

@@ -387,12 +387,24 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(int N, int K, int D, dou
   if (Q_tm) Q_tm[t] = p - (p0[c] + ((double)k * h) * v0[c]);
 }
 
-// move a lexicographic pair (i, j) forward by s pairs; row i+1 of the triangle starts at j = i + 2
-__device__ inline void pair_advance(int& i, int& j, int N, int s) {
+// lexicographic pairs (i, j), i < j: row i + 1 of the triangle starts at j = i + 2.
+// The two advances of the pairwise pass without wrap loops (a divergent while per row and step was a sixth of the
+// kernel's instructions): +1 wraps at most once; +2*PAIR_THREADS wraps once in the long rows of the triangle and falls
+// back to the closed form where the rows are shorter than the stride (i > N - 2*PAIR_THREADS: wave-uniform regions).
+__device__ inline void pair_next(int i, int j, int N, int& i1, int& j1) {
+  i1 = i;
+  j1 = j + 1;
+  if (j1 >= N) {
+    ++i1;
+    j1 = i1 + 1;
+  }
+}
+__device__ inline void pair_advance_far(int& i, int& j, int N, int s, int64_t q_new, int64_t pairs) {
   j += s;
-  while (j >= N && i < N) {
+  if (j >= N) {
     j -= N - 2 - i;
     ++i;
+    if (j >= N) decode_pair(q_new < pairs ? q_new : pairs - 1, N, i, j);
   }
 }
 
@@ -503,11 +515,11 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
       valid[u][1] = FULL || ((off + 1 >= 0) && (off + 1 < nq));
       pi_[u][0] = ci;
       pj_[u][0] = cj;
-      int i1 = ci, j1 = cj;
-      pair_advance(i1, j1, N, 1);
+      int i1, j1;
+      pair_next(ci, cj, N, i1, j1);
       pi_[u][1] = i1;
       pj_[u][1] = j1;
-      pair_advance(ci, cj, N, 2 * PAIR_THREADS);
+      pair_advance_far(ci, cj, N, 2 * PAIR_THREADS, a.q_begin + off + 2 * PAIR_THREADS, a.pairs);
       if (!FULL) {
 #pragma unroll
         for (int e = 0; e < 2; ++e)
@@ -726,7 +738,9 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
   // the k-slice must start 16-byte aligned in global memory for the double2 staging loads: N*D even
   const char* abl = getenv("SCP_PAIR_ABLATE");
   a.ablate = abl ? atoi(abl) : 0;
-  const bool use_lds = lds_bytes <= 64 * 1024 && ((N * D) % 2 == 0) && !(a.ablate & 2);
+  // slices beyond 32 KB cut the occupancy below 5 workgroups per CU and the L1/L2 path wins (measured at 2048 x 50:
+  // 5.43 TB/s without LDS, 4.74 with; at 1024 x 50, 32 KB: 5.0 with, 4.6 without)
+  const bool use_lds = lds_bytes <= 32 * 1024 && ((N * D) % 2 == 0) && !(a.ablate & 2);
   dim3 grid(scp_cdiv(nq + 1, PAIR_ROWS), K);
   dim3 block(PAIR_THREADS);
   SCP_HIP_CHECK(ctx, hipEventRecord(ctx->pair_ev0, ctx->stream));

@@ -37,6 +37,22 @@ __global__ void wr_chunk2d(double* a, double* b, double* c, size_t nq, int steps
     }
   }
 }
+typedef double d2_t __attribute__((ext_vector_type(2)));
+// pattern C with non-temporal stores
+__global__ void wr_chunk2d_nt(double* a, double* b, double* c, size_t nq, int steps) {
+  size_t slice0 = (size_t)blockIdx.y * nq;
+  size_t c0 = (size_t)blockIdx.x * 256 * 2 * steps;
+  for (int s = 0; s < steps; ++s) {
+    size_t o = c0 + (size_t)s * 512 + 2 * threadIdx.x;
+    if (o + 1 < nq) {
+      size_t r = slice0 + o;
+      d2_t v = {(double)r, 1.0};
+      __builtin_nontemporal_store(v, reinterpret_cast<d2_t*>(a + r));
+      __builtin_nontemporal_store(v, reinterpret_cast<d2_t*>(b + r));
+      __builtin_nontemporal_store(v, reinterpret_cast<d2_t*>(c + r));
+    }
+  }
+}
 __global__ void rd_linear(const double2* a, const double2* b, const double2* c, size_t n2, double* out) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n2) { double2 x = a[t], y = b[t], z = c[t]; if (x.x + y.x + z.x == -1.0) out[0] = 1.0; }
@@ -56,6 +72,8 @@ int main() {
   time("wr_linear", [&] { hipLaunchKernelGGL(wr_linear, dim3((n / 2 + 255) / 256), dim3(256), 0, 0, (double2*)a, (double2*)b, (double2*)c, n / 2); });
   time("wr_chunk8", [&] { hipLaunchKernelGGL(wr_chunk, dim3((n + 4095) / 4096), dim3(256), 0, 0, a, b, c, n, 8); });
   time("wr_chunk2d", [&] { hipLaunchKernelGGL(wr_chunk2d, dim3((nq + 4095) / 4096, K), dim3(256), 0, 0, a, b, c, nq, 8); });
+  time("wr_chunk2d16", [&] { hipLaunchKernelGGL(wr_chunk2d, dim3((nq + 8191) / 8192, K), dim3(256), 0, 0, a, b, c, nq, 16); });
+  time("wr_c2d16_nt", [&] { hipLaunchKernelGGL(wr_chunk2d_nt, dim3((nq + 8191) / 8192, K), dim3(256), 0, 0, a, b, c, nq, 16); });
   time("wr_chunk1", [&] { hipLaunchKernelGGL(wr_chunk, dim3((n + 511) / 512), dim3(256), 0, 0, a, b, c, n, 1); });
   time("rd_linear", [&] { hipLaunchKernelGGL(rd_linear, dim3((n / 2 + 255) / 256), dim3(256), 0, 0, (const double2*)a, (const double2*)b, (const double2*)c, n / 2, out); });
   return 0;

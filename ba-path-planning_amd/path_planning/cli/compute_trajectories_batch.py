@@ -45,13 +45,17 @@ def trial_seed(cfg, N, trial):
     return int(cfg["rng_seed"]) + 1000 * N + trial
 
 
-def run_single_trial(N, cfg, rng=None, seed=None, device=None):
-    """One SCP solve for N vehicles -> result record (compute_trajectories_batch.py:28-67)."""
+def make_scenario(N, cfg, seed=None):
+    """Start / goal positions and the space box of one trial (compute_trajectories_batch.py:36-41)."""
     if cfg.get("scenario", "reference") == "grid-swap":
-        init_pos, final_pos, space = generate_grid_swap(N, seed=seed or 0, dim=cfg.get("dim", 2))
-    else:
-        init_pos, final_pos = generate_positions(N, cfg["min_distance"], seed=seed)
-        space = cfg["space_dims"]
+        return generate_grid_swap(N, seed=seed or 0, dim=cfg.get("dim", 2))
+    init_pos, final_pos = generate_positions(N, cfg["min_distance"], seed=seed)
+    return init_pos, final_pos, cfg["space_dims"]
+
+
+def run_single_trial(N, cfg, rng=None, seed=None, device=None, scenario=None):
+    """One SCP solve for N vehicles -> result record (compute_trajectories_batch.py:28-67)."""
+    init_pos, final_pos, space = scenario if scenario is not None else make_scenario(N, cfg, seed)
     solver = None
     t0 = time.perf_counter()
     status = "success"
@@ -180,18 +184,27 @@ def main(argv=None):
         print(f"Max SCP iterations: {cfg['max_iterations']}")
         print()
 
+    jobs = jobs_for_rank(cfg, rank, world)
+    # scenarios first: the rejection sampling of the grid-swap generator (0.1-0.3 s of host time per scenario at
+    # N = 128) would otherwise be what the scenarios/s figure measures
+    t_gen = time.perf_counter()
+    scenarios = {}
+    for N, trial in jobs:
+        seed = trial_seed(cfg, N, trial)
+        if seed is not None:
+            np.random.seed(seed)
+        scenarios[(N, trial)] = make_scenario(N, cfg, seed)
+    t_gen = time.perf_counter() - t_gen
+
     def one_job(job):
         N, trial = job
         seed = trial_seed(cfg, N, trial)
-        if seed is not None and args.streams == 1:
-            np.random.seed(seed)
-        res = run_single_trial(N, cfg, rng=np.random, seed=seed, device=local_rank)
+        res = run_single_trial(N, cfg, rng=np.random, seed=seed, device=local_rank, scenario=scenarios[job])
         res["trial_index"] = trial
         status_str = "OK" if res["status"] == "success" else f"ERR ({res['error']})"
         print(f"  [rank {rank}] N={N} trial {trial+1:02d}/{cfg['trials_per_N']}  time = {res['time_sec']:.3f}s  [{status_str}]")
         return res
 
-    jobs = jobs_for_rank(cfg, rank, world)
     t_all = time.perf_counter()
     if args.streams <= 1:
         runs = [one_job(j) for j in jobs]
@@ -217,7 +230,7 @@ def main(argv=None):
     wall = time.perf_counter() - t_all
     if jobs:
         print(f"  [rank {rank}] {len(jobs)} scenarios in {wall:.2f}s wall = {len(jobs)/wall:.1f} scenarios/s "
-              f"({args.streams} stream(s))")
+              f"({args.streams} stream(s); scenario generation {t_gen:.2f}s before the clock)")
 
     if world > 1:
         import torch.distributed as dist

@@ -131,12 +131,18 @@ def generate_grid_swap(n_agents, seed=0, pitch=2.0, jitter=0.2, block=4, dim=2, 
             T = 256
             perm = np.argsort(rng.random((T, m)), axis=1)
             g = cell[idx[perm]] * pitch + rng.uniform(-jitter, jitter, size=(T, m, 2))
+            # closest approach of the straight-line motions of every pair, per coordinate (a reduction over a
+            # length-2 axis costs numpy more than the arithmetic): r(s) = r0 + s dr, s in [0, 1]
             a = xy[idx]
-            r0 = a[None, :, None, :] - a[None, None, :, :]
-            dr = (g[:, :, None, :] - g[:, None, :, :]) - r0
-            den = np.sum(dr * dr, axis=3)
-            sp = np.clip(-np.sum(r0 * dr, axis=3) / np.where(den > 0, den, 1.0), 0.0, 1.0)
-            d = np.linalg.norm(r0 + sp[..., None] * dr, axis=3)
+            r0x = a[:, 0][:, None] - a[:, 0][None, :]
+            r0y = a[:, 1][:, None] - a[:, 1][None, :]
+            drx = (g[:, :, None, 0] - g[:, None, :, 0]) - r0x
+            dry = (g[:, :, None, 1] - g[:, None, :, 1]) - r0y
+            den = drx * drx + dry * dry
+            sp = np.clip(-(r0x * drx + r0y * dry) / np.where(den > 0, den, 1.0), 0.0, 1.0)
+            cx = r0x + sp * drx
+            cy = r0y + sp * dry
+            d = np.sqrt(cx * cx + cy * cy)
             dmin = np.where(off[None], d, np.inf).reshape(T, -1).min(axis=1)
             ok = np.nonzero(dmin >= min_sep)[0]
             pick = int(ok[0]) if ok.size else int(np.argmax(dmin))

@@ -440,54 +440,28 @@ __global__ __launch_bounds__(256) void fused_row_update_kernel(int64_t nW, int64
 }
 
 // =====================================================================================================
-// Single-PCG-step pipeline (settings.cg_iters == 1, the default): 4 launches per ADMM step.
+// Single-PCG-step pipeline (settings.cg_iters == 1, the default): 3 launches per ADMM step.
 //
-//   x~ = x + a p,  p = Minv r,  r = rhs - H x,  a = (r.p) / (p.H p),   p.H p = p.(H_f p) + rho sum_rows (eta.dQp)^2
+//   x~ = x + a p,  p = Minv r,  r = rhs - H x,  a = (r.p) / (p.H p),   p.H p = r.p + rho sum_rows (eta.dQp)^2
 //
-// so neither H p nor a second scatter is needed, and because x+ = alpha x~ + (1-alpha) x the slab Qx = S0 x follows
-// the recurrence Qx+ = alpha Qt + (1-alpha) Qx (refreshed exactly at every termination check).  Per step:
-//   colA     : W; r = sigma x + F^T W - H_f x + S0^T G (four products side by side); [p; Qp] = [Minv; S0 Minv] r;
-//              partials r.p (H_f p = r, so p.H_f p = r.p); G = 0
-//   rows_sq  : partials rho (eta.dQp)^2
-//   post1    : a; x~ = x + a p; z~ = F x~, Qt = S0 x~; fixed rows' z, y; x+; Qx+
-//   rows_ui  : collision rows' z, y from Qt; then G += eta (rho zc - yc - rho eta.dQx+)   (next step's scatter)
+// (H_f p = r), so neither H p nor a second scatter is needed.  The slabs Qx = S0 x and Fx = F x are carried:
+// x+ = x + alpha a p gives Qx+ = Qx + alpha a Qp, Fx+ = Fx + alpha a Fp (refreshed exactly at every termination
+// check), which turns r into -2 x + F^T(rho w (z_f - Fx) - y_f) + S0^T G and everything after a into elementwise work:
+//   cg1_col_kernel    : r (wave scans), p = Minv r (MFMA), Qp = S0 p, Fp = F p (wave scans), partials r.p
+//   cg1_rows_sq_kernel: partials rho (eta.dQp)^2
+//   cg1_update_kernel : a; fixed rows' z, y, Fx+; x+, Qx+ (other buffer); collision rows' z, y and the row values
+//                       g = rho zc - yc - rho eta.dQx+ of the next right-hand side (gathered by cg1_col_kernel)
 // =====================================================================================================
 constexpr int SQ_BLOCKS = 128;
 constexpr int CHB = 16;  // operand registers (k steps) held at once by a tile product
 
-// One 16-row tile of  O = A[:, 4 ks0 : ke] . V  with A packed (wg_mm_range); the first CH k-steps' operands can be
-// fetched long before V exists (tile_prefetch at kernel entry, tile_product after the barrier).
+// Operands of the first CHB k-steps of row tile t of a packed matrix (wg_mm_range): fetched at kernel entry, long
+// before the vector they multiply exists.
 template <int CH>
 __device__ inline void tile_prefetch(const double* __restrict__ P, int nks, int t, int ks0, int ks1, double (&a)[CH]) {
   const double* Ap = P + (size_t)t * nks * 64 + (threadIdx.x & 63);
 #pragma unroll
   for (int s = 0; s < CH; ++s) a[s] = Ap[(size_t)min(ks0 + s, ks1 - 1) * 64];
-}
-template <int CH>
-__device__ inline void tile_product(const double* __restrict__ P, int R, int nks, int t, int ks0, int ks1, int ke,
-                                    const double* V, double* O, double (&a)[CH]) {
-  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
-  const double* Ap = P + (size_t)t * nks * 64 + lane;
-  double4_t acc = {0.0, 0.0, 0.0, 0.0};
-  for (int kc = ks0; kc < ks1; kc += CH) {
-    if (kc > ks0) {  // beyond the prefetched chunk (K > 60 only)
-#pragma unroll
-      for (int s = 0; s < CH; ++s) a[s] = Ap[(size_t)min(kc + s, ks1 - 1) * 64];
-    }
-#pragma unroll
-    for (int s = 0; s < CH; ++s) {
-      if (kc + s < ks1) {  // wave-uniform
-        const int kk = 4 * (kc + s) + lk;
-        const double b = kk < ke ? V[kk * CB + li] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b, acc, 0, 0, 0);
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = t * 16 + lk + 4 * r;
-    if (row < R) O[row * CB + li] = acc[r];
-  }
 }
 
 // ---- wave-wide prefix sums over the time index (one wave per column, lane l holds the E consecutive steps

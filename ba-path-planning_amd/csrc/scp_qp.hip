@@ -900,11 +900,18 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
   int cg_total = 0, it = 0;
   double rp = INFINITY, rd = INFINITY;
   while (it < st.max_iter) {
-    ++it;
+    // fixed rows only: every iteration up to the next termination check goes into ONE launch
+    const bool qp0_it = fused && qp->nW == 0;
+    int n_it = 1;
+    if (qp0_it) {
+      n_it = st.check_termination - it % st.check_termination;
+      if (it + n_it > st.max_iter) n_it = st.max_iter - it;
+    }
+    it += n_it;
     const bool will_check = it % st.check_termination == 0 || it >= st.max_iter;
     const bool with_dy = will_check && st.eps_prim_inf > 0.0;
     const bool cg1_it = fused && st.cg_iters == 1 && qp->nW > 0;  // its update kernel emits delta-y itself
-    if (with_dy && !cg1_it) {  // snapshot of the duals: delta-y of this iteration feeds the infeasibility certificate
+    if (with_dy && !cg1_it && !qp0_it) {  // snapshot of the duals: delta-y of this iteration feeds the certificate
       SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->d.dyf, qp->d.yf, (size_t)qp->Rf * qp->C * sizeof(double),
                                         hipMemcpyDeviceToDevice, ctx->stream));
       if (qp->nW > 0)
@@ -912,10 +919,11 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
                                           hipMemcpyDeviceToDevice, ctx->stream));
     }
     if (cg1_it) QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total, with_dy));
+    else if (qp0_it) QP_CHECK(scp_qp_qp0_iterations(qp, n_it, with_dy ? qp->d.dyf : nullptr));
     else if (fused) QP_CHECK(scp_qp_fused_iteration(qp, &cg_total));
     else QP_CHECK(admm_iteration(qp, &cg_total));
     if (will_check) {
-      if (cg1_it) QP_CHECK(scp_qp_fused_residuals(qp, with_dy));
+      if (cg1_it || qp0_it) QP_CHECK(scp_qp_fused_residuals(qp, with_dy));
       else QP_CHECK(residuals(qp, with_dy));
       if (!cg1_it) qp->cg1_ready = false;  // residuals() used G and the Q slabs as scratch (the fused check keeps
                                            // the pipeline's carried state and refreshes S0 x, F x exactly)
@@ -931,7 +939,7 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
       if (with_dy) {  // OSQP's is_primal_infeasible on the unscaled problem
         const double ndy = hs[SL_NDY], supp = hs[SL_SUPP];
         if (ndy > st.eps_prim_inf && supp < -st.eps_prim_inf * ndy) {
-          if (!cg1_it) QP_CHECK(certificate_atdy(qp));  // the fused check has |A^T dy| already
+          if (!cg1_it && !qp0_it) QP_CHECK(certificate_atdy(qp));  // the fused check has |A^T dy| already
           if (qp->h_scal[SL_NATDY] < st.eps_prim_inf * ndy) {
             info->status_val = -3;
             break;

@@ -736,6 +736,158 @@ __global__ __launch_bounds__(256) void cg1_rows_sq_kernel(int64_t nW, int64_t C,
   if (threadIdx.x == 0) part_sq[blockIdx.x] = rho * ((sw[0] + sw[1]) + (sw[2] + sw[3]));
 }
 
+// Fixed rows only (QP#0, or any solve before the first collision row joins): the whole ADMM iteration is column-local,
+//   x~ = H_f^{-1} (sigma x + F^T(rho w z - y)),  z~ = F x~,  relaxation, projection, dual update,
+// so ONE launch runs `nit` iterations (up to the next termination check) with z, y, l, u of a thread's slab rows in
+// registers, x in LDS and the H_f^{-1} operands of a wave's tile resident in registers (K <= 64): four barriers and no
+// global memory traffic per iteration, instead of two launches.
+template <int E>
+__global__ __launch_bounds__(FT) void qp0_col_kernel(int K, int Rf, int64_t C, double rho, double sigma, double alpha,
+                                                      double h, int nit, const double* __restrict__ pMinv,
+                                                      const double* __restrict__ wrow, const double* __restrict__ lf,
+                                                      const double* __restrict__ uf, double* __restrict__ x,
+                                                      double* __restrict__ zf, double* __restrict__ yf,
+                                                      double* __restrict__ dy_out) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int RU = 4 * E;  // slab rows per thread: 64 RU >= Rf = 4K - 1 for K <= 64 E
+  const int RSF = pad_col(Rf), RSK = pad_col(K);
+  double* Wt = lds;              // [16][RSF]  rho w z - y, then F x~
+  double* Xt = Wt + CB * RSF;    // [16][RSK]  x
+  double* Rt = Xt + CB * RSK;    // [16][RSK]  right-hand side
+  double* Pt = Rt + CB * RSK;    // [16][RSK]  x~
+  const int64_t c0 = (int64_t)blockIdx.x * CB;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = threadIdx.x & 15, kg = threadIdx.x >> 4;
+  const bool cok = c0 + c < C;
+  const int tK = (K + 15) >> 4, nks = (K + 3) >> 2;
+  const double hh = h * h;
+  double aM[CHB];
+  tile_prefetch<CHB>(pMinv, nks, wave < tK ? wave : 0, 0, nks, aM);
+  double z[RU], y[RU], lo[RU], hi[RU], rw[RU];
+#pragma unroll
+  for (int u = 0; u < RU; ++u) {
+    const int r = kg + u * (FT / CB);
+    z[u] = y[u] = lo[u] = hi[u] = 0.0;
+    rw[u] = 1.0;
+    if (cok && r < Rf) {
+      const int64_t g = (int64_t)r * C + c0 + c;
+      z[u] = zf[g]; y[u] = yf[g]; lo[u] = lf[g]; hi[u] = uf[g];
+      rw[u] = rho * wrow[r];
+    }
+  }
+  for (int k = kg; k < K; k += FT / CB) Xt[c * RSK + k] = cok ? x[(int64_t)k * C + c0 + c] : 0.0;
+  for (int it = 0; it < nit; ++it) {
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int r = kg + u * (FT / CB);
+      if (r < Rf) Wt[c * RSF + r] = rw[u] * z[u] - y[u];
+    }
+    __syncthreads();
+    {  // right-hand side: time steps in descending order (reverse cumulative sums as ascending scans)
+      const double* Wc = Wt + wave * RSF;
+      const int KM = 64 * E - 1;
+      double wj[E], wa[E], u1[E], u2[E], xk[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int k = KM - (lane * E + e);
+        const bool ok = k < K;
+        wj[e] = k < K - 1 ? Wc[k] : 0.0;
+        wa[e] = ok ? Wc[K - 1 + k] : 0.0;
+        const double wv = ok ? Wc[2 * K - 1 + k] : 0.0;
+        u2[e] = ok ? Wc[3 * K - 1 + k] : 0.0;
+        xk[e] = ok ? Xt[wave * RSK + k] : 0.0;
+        u1[e] = h * wv + 0.5 * hh * u2[e];
+      }
+      double d1[E], d2[E], s1[E], s2[E], wjp[E];
+      wave_scan<E>(u1, d1, s1);
+      wave_scan<E>(u2, s1, s2);
+      wave_scan<E>(s1, s2, d2);
+      wave_next<E>(wj, wjp);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int k = KM - (lane * E + e);
+        if (k < K) Rt[wave * RSK + k] = (((wjp[e] - wj[e]) / h + wa[e]) + d1[e] + hh * d2[e]) + sigma * xk[e];
+      }
+    }
+    __syncthreads();
+    for (int t = wave; t < tK; t += NWV) {  // x~ = H_f^{-1} rhs
+      const int li = lane & 15, lk = lane >> 4;
+      const double* Ap = pMinv + (size_t)t * nks * 64 + lane;
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+      for (int kc = 0; kc < nks; kc += CHB) {
+        if (nks > CHB || t != wave) {  // operands not resident (K > 64)
+#pragma unroll
+          for (int s_ = 0; s_ < CHB; ++s_) aM[s_] = Ap[(size_t)min(kc + s_, nks - 1) * 64];
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < CHB; ++s_) {
+          if (kc + s_ < nks) {  // wave-uniform
+            const int kk = 4 * (kc + s_) + lk;
+            const double b = kk < K ? Rt[li * RSK + kk] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aM[s_], b, acc, 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = t * 16 + lk + 4 * r;
+        if (row < K) Pt[li * RSK + row] = acc[r];
+      }
+    }
+    __syncthreads();
+    {  // z~ = F x~ (forward scans), x+ = alpha x~ + (1 - alpha) x
+      double* Wc = Wt + wave * RSF;
+      double pk[E], c1[E], c2[E], t1[E], t2[E], pn[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        pk[e] = k < K ? Pt[wave * RSK + k] : 0.0;
+      }
+      wave_scan<E>(pk, c1, t1);
+      wave_scan<E>(c1, t2, c2);
+      wave_next<E>(pk, pn);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int k = lane * E + e;
+        if (k < K) {
+          if (k < K - 1) Wc[k] = (pn[e] - pk[e]) / h;
+          Wc[K - 1 + k] = pk[e];
+          Wc[2 * K - 1 + k] = h * c1[e];
+          Wc[3 * K - 1 + k] = hh * (c2[e] + 0.5 * c1[e]);
+          Xt[wave * RSK + k] = alpha * pk[e] + (1.0 - alpha) * Xt[wave * RSK + k];
+        }
+      }
+    }
+    __syncthreads();
+    const bool emit = dy_out != nullptr && it == nit - 1;  // delta-y of the last iteration (infeasibility certificate)
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int r = kg + u * (FT / CB);
+      if (cok && r < Rf) {
+        const double zh = alpha * Wt[c * RSF + r] + (1.0 - alpha) * z[u];
+        const double zn = fmin(fmax(zh + y[u] / rw[u], lo[u]), hi[u]);
+        const double yn = y[u] + rw[u] * (zh - zn);
+        if (emit) dy_out[(int64_t)r * C + c0 + c] = yn - y[u];
+        y[u] = yn;
+        z[u] = zn;
+      }
+    }
+  }
+  __syncthreads();
+  if (cok) {
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int r = kg + u * (FT / CB);
+      if (r < Rf) {
+        const int64_t g = (int64_t)r * C + c0 + c;
+        zf[g] = z[u];
+        yf[g] = y[u];
+      }
+    }
+    for (int k = kg; k < K; k += FT / CB) x[(int64_t)k * C + c0 + c] = Xt[c * RSK + k];
+  }
+}
+
 // step length a = r.p / p.H p  from the per-workgroup partials (p.H_f p = p.r because p = H_f^{-1} r); the same
 // instruction sequence in every 256-thread workgroup, so every workgroup holds the same bits
 __device__ inline double step_length_256(const double* __restrict__ part_rz, int nblk, const double* __restrict__ part_sq) {
@@ -980,6 +1132,30 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
                          d.w_j, d.w_eta, d.w_l, Q, d.zc, d.yc);
     FUSED_LAUNCHED(qp);
   }
+  return SCP_OK;
+}
+
+// `nit` ADMM iterations on the fixed rows alone in one launch (qp->nW == 0); dy_out: where to leave delta-y of the last
+// iteration for scp_qp_fused_residuals (NULL: not needed)
+int scp_qp_qp0_iterations(scp_qp* qp, int nit, double* dy_out) {
+  const QpDev& d = qp->d;
+  hipStream_t s = qp->ctx->stream;
+  const int K = qp->K, Rf = qp->Rf;
+  const int64_t C = qp->C;
+  const int nblk = (int)((C + CB - 1) / CB);
+  const size_t lds = (size_t)CB * (pad_col(Rf) + 3 * pad_col(K)) * sizeof(double);
+  if (K <= 64) {
+    int rc = allow_lds(qp, qp0_col_kernel<1>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(qp0_col_kernel<1>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->rho, qp->st.sigma, qp->st.alpha, qp->h,
+                       nit, d.pMinv, d.wrow, d.lf, d.uf, d.x, d.zf, d.yf, dy_out);
+  } else {
+    int rc = allow_lds(qp, qp0_col_kernel<2>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(qp0_col_kernel<2>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->rho, qp->st.sigma, qp->st.alpha, qp->h,
+                       nit, d.pMinv, d.wrow, d.lf, d.uf, d.x, d.zf, d.yf, dy_out);
+  }
+  FUSED_LAUNCHED(qp);
   return SCP_OK;
 }
 
@@ -1327,7 +1503,7 @@ __device__ inline void column_At(int K, double h, const double* Vc, const double
 //   iteration), |dy|, its support value and |A^T dy| of OSQP's primal infeasibility certificate.
 template <int E>
 __global__ __launch_bounds__(FT) void cg1_resid_col_kernel(int K, int Rf, int64_t C, double h, int N, int D, int with_dy,
-                                                            const double* __restrict__ x, const double* __restrict__ zf,
+                                                            int has_rows, const double* __restrict__ x, const double* __restrict__ zf,
                                                             const double* __restrict__ yf, const double* __restrict__ lf,
                                                             const double* __restrict__ uf, const double* __restrict__ dyf,
                                                             const int* __restrict__ cell_ptr,
@@ -1353,11 +1529,13 @@ __global__ __launch_bounds__(FT) void cg1_resid_col_kernel(int K, int Rf, int64_
   for (int k = kg; k < K; k += FT / CB) {
     double acc = 0.0, acc2 = 0.0, xv = 0.0;
     if (cok) {
-      const int cell = k * N + agent;
-      const int t0 = cell_ptr[cell], t1 = cell_ptr[cell + 1];
-      for (int t = t0; t < t1; ++t) acc += coef[(size_t)t * D + dd_] * gval[t];
-      if (with_dy)
-        for (int t = t0; t < t1; ++t) acc2 += coef[(size_t)t * D + dd_] * gval2[t];
+      if (has_rows) {
+        const int cell = k * N + agent;
+        const int t0 = cell_ptr[cell], t1 = cell_ptr[cell + 1];
+        for (int t = t0; t < t1; ++t) acc += coef[(size_t)t * D + dd_] * gval[t];
+        if (with_dy)
+          for (int t = t0; t < t1; ++t) acc2 += coef[(size_t)t * D + dd_] * gval2[t];
+      }
       xv = x[(int64_t)k * C + c0 + c];
     }
     Gx[c * RSK + k] = acc;
@@ -1530,20 +1708,22 @@ int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
   const int nblk = (int)((C + CB - 1) / CB);
   double* Qx = qp->qx_sel ? d.HQ : d.HQ + nx;
   double* part = qp->h_scal_dev + SL_COUNT;  // [nblk column blocks | RESID_ROW_BLOCKS row blocks][SCP_RESID_STRIDE]
-  hipLaunchKernelGGL(csr_rowval_kernel, dim3((unsigned)((qp->nW + 255) / 256)), dim3(256), 0, s, qp->nW, 1, 0.0, d.zc,
-                     d.yc, (const double*)nullptr, d.pos_i, d.pos_j, d.gval2, with_dy ? d.dyc : (const double*)nullptr,
-                     with_dy ? d.gval3 : (double*)nullptr);
+  const int has_rows = qp->nW > 0 ? 1 : 0;
+  if (has_rows)
+    hipLaunchKernelGGL(csr_rowval_kernel, dim3((unsigned)((qp->nW + 255) / 256)), dim3(256), 0, s, qp->nW, 1, 0.0, d.zc,
+                       d.yc, (const double*)nullptr, d.pos_i, d.pos_j, d.gval2, with_dy ? d.dyc : (const double*)nullptr,
+                       with_dy ? d.gval3 : (double*)nullptr);
   const size_t lds = (size_t)CB * (pad_col(Rf) + 4 * pad_col(K)) * sizeof(double);
   if (K <= 64) {
     int rc = allow_lds(qp, cg1_resid_col_kernel<1>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(cg1_resid_col_kernel<1>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->h, qp->N, qp->D, with_dy ? 1 : 0,
-                       d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval2, d.gval3, Qx, d.fx, part);
+                       has_rows, d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval2, d.gval3, Qx, d.fx, part);
   } else {
     int rc = allow_lds(qp, cg1_resid_col_kernel<2>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(cg1_resid_col_kernel<2>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->h, qp->N, qp->D, with_dy ? 1 : 0,
-                       d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval2, d.gval3, Qx, d.fx, part);
+                       has_rows, d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval2, d.gval3, Qx, d.fx, part);
   }
   double* rpart = part + (size_t)nblk * SCP_RESID_STRIDE;
   if (qp->D == 2)

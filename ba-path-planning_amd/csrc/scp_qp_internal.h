@@ -76,6 +76,8 @@ constexpr int SCP_PART_CAP = 4096;  // capacity of each partial-sum array (colum
 int scp_qp_fused_iteration(scp_qp* qp, int* cg_count);
 // single-PCG-step pipeline (cg_iters == 1 and a non-empty working set): 4 launches per ADMM step
 int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count, bool emit_dy);
+// nW == 0: `nit` complete ADMM iterations in one launch (everything is column-local)
+int scp_qp_qp0_iterations(scp_qp* qp, int nit, double* dy_out);
 // Deterministic A_W^T g into the G slab (valid incidence lists required): mode 0: g = rho_c zc - yc, 1: g = yc,
 // 2: g = vec[n].  Two launches, no atomics.
 int scp_qp_csr_scatter(scp_qp* qp, int mode, const double* vec);

@@ -254,10 +254,12 @@ def test_edge_sizes(n, T, h, dim):
     assert rep["collision_free"] and rep["final_position_error"] < 3e-2
 
 
-@pytest.mark.parametrize("T,K", [(14.0, 70), (26.0, 130)])
+@pytest.mark.parametrize("T,K", [(12.9, 64), (13.1, 65), (14.0, 70), (24.1, 120), (26.0, 130)])
 def test_large_K_paths(T, K):
-    """K = 70: fused column-block kernels with more than 64 KiB of LDS tiles; K = 130 > 120: the generic
-    one-product-per-launch path (the reference's compute-trajectories demo runs K = 500).  Same oracle, same tolerance."""
+    """K = 64 / 65: one / two time steps per lane in the wave scans of the column kernels (and 4 / 8 slab rows per
+    thread in the QP#0 kernel); K = 70, 120: more than 64 KiB of LDS tiles, 120 the largest fused size; K = 130 > 120:
+    the generic one-product-per-launch path (the reference's compute-trajectories demo runs K = 500).  Same oracle,
+    same tolerance."""
     from path_planning.scenarios.position_generator import generate_positions
 
     p0, pf = generate_positions(5, 0.8, seed=2)

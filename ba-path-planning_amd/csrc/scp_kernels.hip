@@ -351,11 +351,12 @@ __device__ inline void atomic_max_double(double* addr, double v) {
 constexpr int PAIR_THREADS = 256;
 constexpr int PAIR_STEPS = 16;                             // steps per thread, 2 adjacent rows per step
 // independent steps in flight per thread: 4 when the slices come through L1/L2 (latency to cover; 179 VGPRs, 2 waves
-// per SIMD), 2 when they sit in LDS (104 VGPRs, 4 waves per SIMD: 110-112 us instead of 122 at 1024 x 50; with 4 steps
-// the L1/L2 path runs 1.63 ms at 4096 x 50, with 2 steps 2.16 ms)
-template <bool USE_LDS>
+// per SIMD) and in the violations pass (streaming reads want the loads in flight), 2 for the store-bound passes with
+// LDS slices (104 VGPRs, 4 waves per SIMD: linearisation 110-118 us instead of 122 at 1024 x 50; with 4 steps the
+// L1/L2 path runs 1.63 ms at 4096 x 50, with 2 steps 2.16 ms)
+template <bool USE_LDS, int MODE>
 struct PairUnroll {
-  static constexpr int value = USE_LDS ? 2 : 4;
+  static constexpr int value = (USE_LDS && MODE != 2 /* MODE_VIOLATIONS */) ? 2 : 4;
 };
 constexpr int PAIR_ROWS = PAIR_THREADS * PAIR_STEPS * 2;   // rows (= pairs at one k) per workgroup
 
@@ -450,7 +451,7 @@ __device__ inline Pt<D> load_pt(const double* base, int idx) {
 // several rows in flight; the selection / first-violation bookkeeping is behind a wave-uniform ballot.
 template <int D, int MODE, bool USE_LDS>
 __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
-  constexpr int PAIR_UNROLL = PairUnroll<USE_LDS>::value;
+  constexpr int PAIR_UNROLL = PairUnroll<USE_LDS, MODE>::value;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int N = a.N;
   const int k = blockIdx.y;

@@ -1264,38 +1264,42 @@ __global__ __launch_bounds__(256) void csr_count_kernel(int64_t nW, int N, const
   atomicAdd(cnt + wk[n] * N + wj[n], 1);
 }
 
-// exclusive scan of cnt[0..ncell) into ptr (in place: cnt and ptr are the same array), cursors = ptr; one workgroup:
-// every thread owns a contiguous run of cells, so the counts are read with all loads in flight; the 1024 run totals
-// are scanned with DPP moves
+// exclusive scan of cnt[0..ncell) into ptr (in place: cnt and ptr are the same array), cursors = ptr; one workgroup,
+// 1024 cells per pass (coalesced), the next pass's counts fetched before this pass's barriers, wave scans on DPP
 template <int CTRL, int ROW_MASK>
 __device__ inline int dpp_mov0_i32(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true);
 }
 __global__ __launch_bounds__(1024) void csr_scan_kernel(int ncell, int* __restrict__ ptr, int* __restrict__ cur) {
   __shared__ int wsum[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int per = (ncell + 1023) / 1024;
-  const int c0 = threadIdx.x * per, c1 = min(c0 + per, ncell);
-  int tot = 0;
-  for (int c = c0; c < c1; ++c) tot += ptr[c];
-  int incl = tot;
-  incl += dpp_mov0_i32<0x111, 0xF>(incl);
-  incl += dpp_mov0_i32<0x112, 0xF>(incl);
-  incl += dpp_mov0_i32<0x114, 0xF>(incl);
-  incl += dpp_mov0_i32<0x118, 0xF>(incl);
-  incl += dpp_mov0_i32<0x142, 0xA>(incl);
-  incl += dpp_mov0_i32<0x143, 0xC>(incl);
-  if (lane == 63) wsum[wave] = incl;
-  __syncthreads();
-  int run = incl - tot;
-  for (int w = 0; w < wave; ++w) run += wsum[w];
-  for (int c = c0; c < c1; ++c) {
-    const int v = ptr[c];
-    ptr[c] = run;
-    cur[c] = run;
-    run += v;
+  int v = (int)threadIdx.x < ncell ? ptr[threadIdx.x] : 0;
+  for (int b0 = 0; b0 < ncell; b0 += 1024) {
+    const int c = b0 + threadIdx.x;
+    const int vn = c + 1024 < ncell ? ptr[c + 1024] : 0;  // (cells of a later pass: not written yet)
+    int incl = v;
+    incl += dpp_mov0_i32<0x111, 0xF>(incl);
+    incl += dpp_mov0_i32<0x112, 0xF>(incl);
+    incl += dpp_mov0_i32<0x114, 0xF>(incl);
+    incl += dpp_mov0_i32<0x118, 0xF>(incl);
+    incl += dpp_mov0_i32<0x142, 0xA>(incl);
+    incl += dpp_mov0_i32<0x143, 0xC>(incl);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = carry_s;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    if (c < ncell) {
+      ptr[c] = base + incl - v;
+      cur[c] = base + incl - v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = base + incl;
+    v = vn;
   }
-  if (threadIdx.x == 1023) ptr[ncell] = run;  // c0 <= ncell for every thread: the last one ends at ncell
+  __syncthreads();
+  if (threadIdx.x == 0) ptr[ncell] = carry_s;
 }
 
 __global__ __launch_bounds__(256) void csr_fill_kernel(int64_t nW, int N, const int* __restrict__ wk,

@@ -568,41 +568,64 @@ __global__ __launch_bounds__(FT) void cg1_col_kernel(int K, int Rf, int64_t C, d
   const int c = threadIdx.x & 15, kg = threadIdx.x >> 4;
   const bool cok = c0 + c < C;
   const int col = (int)(c0 + c), agent = col / D, dd = col - agent * D;
-  double aM[CHB];
-  tile_prefetch<CHB>(pMinv, nks, wave < tK ? wave : 0, 0, nks, aM);
-  for (int k0 = 0; k0 < K; k0 += FT / CB) {
-    const int k = k0 + kg;
+  // Issue order = return order: the incidence-list bounds first (the gather's second hop depends on them), then x and
+  // the slab rows, then the H_f^{-1} operands; the dependent coef / gval loads follow while the rest is in flight.
+  // (Measured: the prologue takes 4.1 us either way -- two round trips to data another XCD wrote in the last launch.)
+  auto gather = [&](int k, double& xv) {  // incidence-list sum of one (time step, column); returns it, loads x
     int g0 = 0, g1 = 0;
-    double xv = 0.0, acc = 0.0;
+    double acc = 0.0;
+    xv = 0.0;
     if (cok && k < K) {
       g0 = cell_ptr[k * N + agent];
       g1 = cell_ptr[k * N + agent + 1];
       xv = x[(int64_t)k * C + c0 + c];
     }
     for (int t = g0; t < g1; ++t) acc += coef[(size_t)t * D + dd] * gval[t];
-    if (k < K) {
-      Gx[c * RSK + k] = acc;
-      Xt[c * RSK + k] = xv;
+    return acc;
+  };
+  int g0 = 0, g1 = 0;
+  double xv0 = 0.0;
+  if (cok && kg < K) {
+    g0 = cell_ptr[kg * N + agent];
+    g1 = cell_ptr[kg * N + agent + 1];
+    xv0 = x[(int64_t)kg * C + c0 + c];
+  }
+  double wz[WU], wf[WU], wy[WU];
+#pragma unroll
+  for (int u = 0; u < WU; ++u) {
+    const int r = kg + u * (FT / CB);
+    wz[u] = wf[u] = wy[u] = 0.0;
+    if (cok && r < Rf) {
+      const int64_t g = (int64_t)r * C + c0 + c;
+      wz[u] = zf[g];
+      wf[u] = Fx[g];
+      wy[u] = yf[g];
     }
   }
-  for (int r0 = 0; r0 < Rf; r0 += WU * (FT / CB)) {
-    double wz[WU], wf[WU], wy[WU];
-#pragma unroll
-    for (int u = 0; u < WU; ++u) {
-      const int r = r0 + kg + u * (FT / CB);
-      wz[u] = wf[u] = wy[u] = 0.0;
-      if (cok && r < Rf) {
-        const int64_t g = (int64_t)r * C + c0 + c;
-        wz[u] = zf[g];
-        wf[u] = Fx[g];
-        wy[u] = yf[g];
-      }
+  double aM[CHB];
+  tile_prefetch<CHB>(pMinv, nks, wave < tK ? wave : 0, 0, nks, aM);
+  {
+    double acc = 0.0;
+    for (int t = g0; t < g1; ++t) acc += coef[(size_t)t * D + dd] * gval[t];
+    if (kg < K) {
+      Gx[c * RSK + kg] = acc;
+      Xt[c * RSK + kg] = xv0;
     }
+  }
 #pragma unroll
-    for (int u = 0; u < WU; ++u) {
-      const int r = r0 + kg + u * (FT / CB);
-      if (r < Rf) Wt[c * RSF + r] = rho * wrow[r] * (wz[u] - wf[u]) - wy[u];
-    }
+  for (int u = 0; u < WU; ++u) {
+    const int r = kg + u * (FT / CB);
+    if (r < Rf) Wt[c * RSF + r] = rho * wrow[r] * (wz[u] - wf[u]) - wy[u];
+  }
+  for (int k = kg + FT / CB; k < K; k += FT / CB) {  // K > 64
+    double xv;
+    const double acc = gather(k, xv);
+    Gx[c * RSK + k] = acc;
+    Xt[c * RSK + k] = xv;
+  }
+  for (int r = kg + WU * (FT / CB); r < Rf; r += FT / CB) {  // Rf > 256
+    const int64_t g = (int64_t)r * C + c0 + c;
+    Wt[c * RSF + r] = cok ? rho * wrow[r] * (zf[g] - Fx[g]) - yf[g] : 0.0;
   }
   __syncthreads();
   PHASE_MARK(1);

@@ -271,6 +271,20 @@ def test_large_K_paths(T, K):
     np.testing.assert_allclose(traj["positions"], out["positions"], rtol=0, atol=TOL)
 
 
+def test_large_K_3d():
+    """K = 65 in 3-D: two time steps per lane in the wave scans together with the D = 3 row kernels (27 columns: two
+    column blocks, the second one partly empty)."""
+    from path_planning.scenarios.position_generator import generate_grid_swap
+
+    p0, pf, space = generate_grid_swap(9, seed=21, dim=3)
+    s, traj = solve_gpu(9, 13.1, 0.2, 0.8, space, p0, pf, max_iterations=2, dim=3)
+    prob = so.make_problem(9, 13.1, 0.2, 0.8, space, p0, pf)
+    assert prob.K == 65 and prob.D == 3
+    out = qo.scp_solve(prob, 2, qo.Settings(max_iter=10000))
+    assert s.last_info["n_iterations"] == out["iterations"]
+    np.testing.assert_allclose(traj["positions"], out["positions"], rtol=0, atol=TOL)
+
+
 @pytest.mark.parametrize("cg", [1, 2])
 @pytest.mark.parametrize("kind,n,seed", [("ref", 6, 11), ("ref", 8, 12), ("ref", 12, 13), ("ref", 16, 14),
                                          ("grid", 25, 15), ("grid", 36, 16), ("grid3d", 27, 17)])

@@ -1288,21 +1288,28 @@ __global__ __launch_bounds__(256) void csr_count_kernel(int64_t nW, int N, const
 }
 
 // exclusive scan of cnt[0..ncell) into ptr (in place: cnt and ptr are the same array), cursors = ptr; one workgroup,
-// 1024 cells per pass (coalesced), the next pass's counts fetched before this pass's barriers, wave scans on DPP
+// 4096 cells per pass (coalesced), the next pass's counts fetched before this pass's barriers, wave scans on DPP
 template <int CTRL, int ROW_MASK>
 __device__ inline int dpp_mov0_i32(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true);
 }
 __global__ __launch_bounds__(1024) void csr_scan_kernel(int ncell, int* __restrict__ ptr, int* __restrict__ cur) {
+  // 4 consecutive cells per thread and pass: 4096 cells per pass
   __shared__ int wsum[16];
   __shared__ int carry_s;
   if (threadIdx.x == 0) carry_s = 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int v = (int)threadIdx.x < ncell ? ptr[threadIdx.x] : 0;
-  for (int b0 = 0; b0 < ncell; b0 += 1024) {
-    const int c = b0 + threadIdx.x;
-    const int vn = c + 1024 < ncell ? ptr[c + 1024] : 0;  // (cells of a later pass: not written yet)
-    int incl = v;
+  auto load4 = [&](int c, int (&v)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = c + e < ncell ? ptr[c + e] : 0;
+  };
+  int v[4], vn[4];
+  load4(4 * (int)threadIdx.x, v);
+  for (int b0 = 0; b0 < ncell; b0 += 4096) {
+    const int c = b0 + 4 * (int)threadIdx.x;
+    load4(c + 4096, vn);  // (cells of a later pass: not written yet)
+    const int tot = (v[0] + v[1]) + (v[2] + v[3]);
+    int incl = tot;
     incl += dpp_mov0_i32<0x111, 0xF>(incl);
     incl += dpp_mov0_i32<0x112, 0xF>(incl);
     incl += dpp_mov0_i32<0x114, 0xF>(incl);
@@ -1313,13 +1320,19 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int ncell, int* __restri
     __syncthreads();
     int base = carry_s;
     for (int w = 0; w < wave; ++w) base += wsum[w];
-    if (c < ncell) {
-      ptr[c] = base + incl - v;
-      cur[c] = base + incl - v;
+    int run = base + incl - tot;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (c + e < ncell) {
+        ptr[c + e] = run;
+        cur[c + e] = run;
+      }
+      run += v[e];
     }
     __syncthreads();
     if (threadIdx.x == 1023) carry_s = base + incl;
-    v = vn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = vn[e];
   }
   __syncthreads();
   if (threadIdx.x == 0) ptr[ncell] = carry_s;

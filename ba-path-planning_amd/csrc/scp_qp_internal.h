@@ -74,7 +74,7 @@ constexpr int SCP_INV_LDS_MAX_K = 96;  // [H_f | I] (K x 2K doubles) resident in
 constexpr int SCP_FUSED_MAX_K = 120;  // (6K + 4K-1) * 128 B of LDS tiles <= 160 KiB (limit raised above 64 KiB)
 constexpr int SCP_PART_CAP = 4096;  // capacity of each partial-sum array (column blocks of the fused path)
 int scp_qp_fused_iteration(scp_qp* qp, int* cg_count);
-// single-PCG-step pipeline (cg_iters == 1 and a non-empty working set): 4 launches per ADMM step
+// single-PCG-step pipeline (cg_iters == 1 and a non-empty working set): 3 launches per ADMM step
 int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count, bool emit_dy);
 // nW == 0: `nit` complete ADMM iterations in one launch (everything is column-local)
 int scp_qp_qp0_iterations(scp_qp* qp, int nit, double* dy_out);

@@ -1,7 +1,7 @@
 """Developer tool: where one workgroup of the column-block ADMM kernels spends its time.
 
 Needs the profiling build (`make -C ba-path-planning_amd/csrc prof`), which stamps a 100 MHz wall clock at the
-phase boundaries of cg1_colA_kernel / cg1_post_kernel (middle workgroup, last launch).  Not part of the product path.
+phase boundaries of cg1_col_kernel / cg1_resid_col_kernel (middle workgroup, last launch).  Not part of the product path.
 """
 import ctypes as C
 import os

@@ -767,7 +767,8 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
   qp->rho = s->rho;
   carve(qp->d, workspace, K, qp->C, row_capacity, D);
   qp->check_seq = 0;
-  if (hipHostMalloc(&qp->h_scal, (SL_COUNT + SCP_RESID_CAP + 1) * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+  if (hipHostMalloc(&qp->h_scal, (SL_COUNT + SCP_RESID_CAP + 1) * sizeof(double),
+                    hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer((void**)&qp->h_scal_dev, qp->h_scal, 0) != hipSuccess) {
     delete qp;
     return scp_fail(ctx, SCP_ERR_HIP, "qp_create: hipHostMalloc failed");

@@ -164,6 +164,12 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
+        # more ranks than GPUs is a feature: launches of one process serialise in the HIP runtime (8 streams in ONE
+        # process top out at ~1.6x one stream at N = 128), several processes per GPU do not
+        import torch
+
+        local_rank %= max(torch.cuda.device_count(), 1)
+    if world > 1:
         import torch.distributed as dist
 
         if not dist.is_initialized():

@@ -930,6 +930,38 @@ __device__ inline double step_length_256(const double* __restrict__ part_rz, int
   return (pHp > 0.0 && rz != 0.0) ? rz / pHp : 0.0;
 }
 
+// The same step length with p.Hp's row term summed by the caller itself (every workgroup redundantly, in the same order
+// -> the same bits): for small working sets (nW <= SQ_INLINE_MAX) this saves the cg1_rows_sq_kernel launch -- a third
+// of an iteration's launches and ~5 us of its latency when a solve is launch bound (N <= ~256).
+constexpr int SQ_INLINE_MAX = 2048;
+template <int D>
+__device__ inline double step_length_inline_256(const double* __restrict__ part_rz, int nblk, int64_t nW, int64_t C, double rho_c,
+                                                const int* __restrict__ wk, const int* __restrict__ wi,
+                                                const int* __restrict__ wj, const double* __restrict__ weta,
+                                                const double* __restrict__ Qp) {
+  __shared__ double sw[2][4];
+  double v = 0.0, q = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) v += part_rz[b];
+  for (int64_t n = threadIdx.x; n < nW; n += 256) {
+    const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
+    const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
+    double ax = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) ax += weta[n * D + d] * (Qp[bi + d] - Qp[bj + d]);
+    q += ax * ax;
+  }
+  v = wave_incl_sum(v);
+  q = wave_incl_sum(q);
+  if ((threadIdx.x & 63) == 63) {
+    sw[0][threadIdx.x >> 6] = v;
+    sw[1][threadIdx.x >> 6] = q;
+  }
+  __syncthreads();
+  const double rz = (sw[0][0] + sw[0][1]) + (sw[0][2] + sw[0][3]);
+  const double pHp = rz + rho_c * ((sw[1][0] + sw[1][1]) + (sw[1][2] + sw[1][3]));
+  return (pHp > 0.0 && rz != 0.0) ? rz / pHp : 0.0;
+}
+
 constexpr int UPD_RPT = 2;  // slab rows per thread in the elementwise part of cg1_update_kernel (32 rows per workgroup)
 
 // Launch 3 of 3: everything that follows the step length, elementwise.  Workgroups [0, eblocks): 32 slab
@@ -956,7 +988,7 @@ __global__ __launch_bounds__(256) void cg1_update_kernel(int K, int Rf, int64_t 
                                                           double* __restrict__ zc, double* __restrict__ yc,
                                                           const int* __restrict__ pos_i, const int* __restrict__ pos_j,
                                                           double* __restrict__ gval, double* __restrict__ dyf,
-                                                          double* __restrict__ dyc) {
+                                                          double* __restrict__ dyc, int inline_sq) {
   // all operands are loaded BEFORE the step length is reduced (one memory round trip for both)
   if ((int)blockIdx.x < eblocks) {
     const int seg = blockIdx.x / nblk8, blk = blockIdx.x - seg * nblk8;
@@ -978,7 +1010,8 @@ __global__ __launch_bounds__(256) void cg1_update_kernel(int K, int Rf, int64_t 
         v0[u] = x[g]; v1[u] = pdir[g]; v2[u] = Qx[g]; v3[u] = Qp[g];
       }
     }
-    const double a = step_length_256(part_rz, nblk, part_sq);
+    const double a = inline_sq ? step_length_inline_256<D>(part_rz, nblk, nW, C, rho_c, wk, wi, wj, weta, Qp)
+                               : step_length_256(part_rz, nblk, part_sq);
     const double aa = alpha * a;
     if (!live) return;
 #pragma unroll
@@ -1017,7 +1050,8 @@ __global__ __launch_bounds__(256) void cg1_update_kernel(int K, int Rf, int64_t 
     z = zc[n]; y = yc[n]; lo = wl[n];
     posi = pos_i[n]; posj = pos_j[n];
   }
-  const double a = step_length_256(part_rz, nblk, part_sq);
+  const double a = inline_sq ? step_length_inline_256<D>(part_rz, nblk, nW, C, rho_c, wk, wi, wj, weta, Qp)
+                             : step_length_256(part_rz, nblk, part_sq);
   const double aa = alpha * a;
   if (!live) return;
   double tc = 0.0, ax = 0.0;
@@ -1248,24 +1282,27 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count, bool emit_dy) {
   }
   FUSED_LAUNCHED(qp);
   const dim3 rblock(256);
-  if (qp->D == 2)
-    hipLaunchKernelGGL(cg1_rows_sq_kernel<2>, dim3(SQ_BLOCKS), rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
-                       d.w_eta, Qp, part_sq);
-  else
-    hipLaunchKernelGGL(cg1_rows_sq_kernel<3>, dim3(SQ_BLOCKS), rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
-                       d.w_eta, Qp, part_sq);
-  FUSED_LAUNCHED(qp);
+  const int inline_sq = qp->nW <= SQ_INLINE_MAX ? 1 : 0;  // small working set: the update kernel sums p.Hp's row term itself
+  if (!inline_sq) {
+    if (qp->D == 2)
+      hipLaunchKernelGGL(cg1_rows_sq_kernel<2>, dim3(SQ_BLOCKS), rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
+                         d.w_eta, Qp, part_sq);
+    else
+      hipLaunchKernelGGL(cg1_rows_sq_kernel<3>, dim3(SQ_BLOCKS), rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
+                         d.w_eta, Qp, part_sq);
+    FUSED_LAUNCHED(qp);
+  }
   const int nblk8 = (nblk + 7) & ~7;
   const int eblocks = nblk8 * ((Rf + K + 16 * UPD_RPT - 1) / (16 * UPD_RPT));
   const dim3 ugrid((unsigned)(eblocks + (qp->nW + 255) / 256));
   if (qp->D == 2)
     hipLaunchKernelGGL(cg1_update_kernel<2>, ugrid, rblock, 0, s, K, Rf, C, nblk, eblocks, nblk8, qp->rho, rho_c, qp->st.alpha,
                        part_rz, part_sq, d.wrow, d.lf, d.uf, d.zf, d.yf, d.fx, Fp, d.x, d.p, Qp, Qx, Qn, qp->nW, d.w_k,
-                       d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc, d.pos_i, d.pos_j, d.gval, dyf, dyc);
+                       d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc, d.pos_i, d.pos_j, d.gval, dyf, dyc, inline_sq);
   else
     hipLaunchKernelGGL(cg1_update_kernel<3>, ugrid, rblock, 0, s, K, Rf, C, nblk, eblocks, nblk8, qp->rho, rho_c, qp->st.alpha,
                        part_rz, part_sq, d.wrow, d.lf, d.uf, d.zf, d.yf, d.fx, Fp, d.x, d.p, Qp, Qx, Qn, qp->nW, d.w_k,
-                       d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc, d.pos_i, d.pos_j, d.gval, dyf, dyc);
+                       d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc, d.pos_i, d.pos_j, d.gval, dyf, dyc, inline_sq);
   FUSED_LAUNCHED(qp);
   qp->qx_sel ^= 1;
   ++*cg_count;

@@ -11,6 +11,8 @@
 // for K > 128 and as the use_mfma = 0/2 reference); the arithmetic is the same, statement by statement.
 #include "scp_qp_internal.h"
 #include <chrono>
+#include <mutex>
+#include <unordered_map>
 #include <cstdlib>
 
 namespace {
@@ -1097,8 +1099,16 @@ __global__ __launch_bounds__(256) void cg1_rows_init_kernel(int64_t nW, int64_t 
 template <typename Kern>
 int allow_lds(scp_qp* qp, Kern kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return SCP_OK;
-  SCP_HIP_CHECK(qp->ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  // the attribute belongs to the kernel, not to the launch: raised once per kernel (and again only for a larger
+  // request) instead of on every iteration
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> allowed;
+  const void* key = reinterpret_cast<const void*>(kernel);
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = allowed[key];
+  if (have >= bytes) return SCP_OK;
+  SCP_HIP_CHECK(qp->ctx, hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  have = bytes;
   return SCP_OK;
 }
 

@@ -1833,7 +1833,9 @@ int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     while (*flag != seq) {
+#if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
+#endif
       if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
     }
     if (*flag != seq) SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // a fault surfaces here

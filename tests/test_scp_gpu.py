@@ -296,7 +296,7 @@ def test_scp_sweep_vs_oracle(kind, n, seed, cg):
     during the transient -- on nearly degenerate QPs (one pair active over consecutive steps) it amplifies the
     1e-13 difference between two summation orders (numpy vs MFMA) by up to 1e7 before both iterates converge to
     the same solution -- so the two implementations may stop 25 steps apart at two equally valid eps = 1e-3
-    solutions: the tolerance there is the ADMM termination tolerance.  (tools/debug_qp.py shows the growth; the GPU
+    solutions: the tolerance there is the ADMM termination tolerance.  (tests/tools/debug_qp.py shows the growth; the GPU
     itself is deterministic run to run.)"""
     from path_planning.scenarios.position_generator import generate_grid_swap
 

@@ -11,6 +11,7 @@
 
 struct scp_ctx {
   int device;
+  int n_cu;  // compute units of the device (resident-workgroup limit of the persistent kernels)
   hipStream_t stream;
   char err[512];
   // small device scratch for reductions / host read-back
@@ -52,6 +53,11 @@ static inline int scp_fail(scp_ctx* ctx, int code, const char* fmt, ...) {
 
 static inline int64_t scp_pairs(int N) { return (int64_t)N * (N - 1) / 2; }
 static inline int scp_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Raise a kernel's dynamic-LDS limit to at least `bytes` (gfx950: up to 160 KiB per workgroup).  The attribute belongs to
+// the (device, kernel) pair and is only ever raised, so concurrent solves of different sizes cannot lower each other's
+// limit.  Thread safe.
+hipError_t scp_raise_lds_limit(int device, const void* kernel, size_t bytes);
 
 // ---- internal launchers (time-major device layout [K][C], C = N*D) --------------------------------
 // Y[R][C] = alpha * A[R][M] X[M][C] + beta * Y   (row-major; A small and L2 resident)

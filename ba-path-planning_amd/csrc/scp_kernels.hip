@@ -5,7 +5,10 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 // ----------------------------------------------------------------------------------------------------
 // context
@@ -20,6 +23,7 @@ extern "C" int scp_ctx_create(int device, void* hip_stream, scp_ctx** out) {
   memset(ctx, 0, sizeof(*ctx));
   ctx->device = device;
   ctx->stream = (hipStream_t)hip_stream;
+  if (hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ctx->n_cu = 0;
   if (hipMalloc(&ctx->d_scratch, 64 * sizeof(double)) != hipSuccess ||
       hipHostMalloc(&ctx->h_scratch, 64 * sizeof(double)) != hipSuccess ||
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
@@ -45,6 +49,17 @@ extern "C" void scp_ctx_destroy(scp_ctx* ctx) {
   (void)hipEventDestroy(ctx->pair_ev0);
   (void)hipEventDestroy(ctx->pair_ev1);
   delete ctx;
+}
+
+hipError_t scp_raise_lds_limit(int device, const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> allowed;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = allowed[std::make_pair(device, kernel)];
+  if (have >= bytes) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
 }
 
 extern "C" const char* scp_last_error(const scp_ctx* ctx) { return ctx ? ctx->err : "null context"; }

@@ -510,6 +510,7 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.gval3 = c.take<double>((size_t)2 * cap);
   d.pos_i = c.take<int>((size_t)cap);
   d.pos_j = c.take<int>((size_t)cap);
+  d.sync_words = c.take<unsigned long long>(SCP_SYNC_WORDS);
   return c.off;
 }
 
@@ -572,8 +573,7 @@ int build_kkt(scp_qp* qp) {
   if (K <= SCP_INV_LDS_MAX_K) {
     const size_t lds = ((size_t)K * 2 * K + 3 * K) * sizeof(double);
     if (lds > 64 * 1024)
-      SCP_HIP_CHECK(qp->ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(spd_inverse_lds_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SCP_HIP_CHECK(qp->ctx, scp_raise_lds_limit(qp->ctx->device, reinterpret_cast<const void*>(spd_inverse_lds_kernel), lds));
     hipLaunchKernelGGL(spd_inverse_lds_kernel, dim3(1), dim3(1024), lds, s, K, d.Hf, d.Minv);
   } else {
     hipLaunchKernelGGL(spd_inverse_kernel, dim3(1), dim3(1024), (size_t)3 * K * sizeof(double), s, K, d.aug, d.Minv);
@@ -728,6 +728,7 @@ extern "C" void scp_qp_default_settings(scp_qp_settings* s) {
   s->use_mfma = 1;
   s->rho_col_scale = 10.0;
   s->eps_prim_inf = 1e-4;
+  s->persistent = 1;
 }
 
 extern "C" size_t scp_qp_workspace_bytes(int N, int K, int D, int64_t row_capacity) {
@@ -740,7 +741,7 @@ static int check_settings(scp_ctx* ctx, const scp_qp_settings* s) {
   SCP_REQUIRE(ctx, s->rho > 0 && s->sigma > 0 && s->alpha > 0 && s->alpha < 2 && s->rho_eq_scale > 0 &&
                        s->rho_col_scale > 0,
               "qp settings: rho/sigma/alpha out of range");
-  SCP_REQUIRE(ctx, s->max_iter > 0 && s->check_termination > 0 && s->cg_iters >= 0, "qp settings: bad iteration counts");
+  SCP_REQUIRE(ctx, s->max_iter > 0 && s->check_termination > 0 && s->cg_iters >= 1, "qp settings: bad iteration counts");
   return SCP_OK;
 }
 
@@ -767,13 +768,19 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
   qp->rho = s->rho;
   carve(qp->d, workspace, K, qp->C, row_capacity, D);
   qp->check_seq = 0;
-  if (hipHostMalloc(&qp->h_scal, (SL_COUNT + SCP_RESID_CAP + 1) * sizeof(double),
+  qp->persist_off = false;
+  qp->persist_cap_nW = -1;
+  qp->persist_cap = 0;
+  qp->persist_epoch = 0;
+  if (hipHostMalloc(&qp->h_scal, (SL_COUNT + SCP_RESID_CAP + 2) * sizeof(double),
                     hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer((void**)&qp->h_scal_dev, qp->h_scal, 0) != hipSuccess) {
     delete qp;
     return scp_fail(ctx, SCP_ERR_HIP, "qp_create: hipHostMalloc failed");
   }
-  memset(qp->h_scal, 0, (SL_COUNT + SCP_RESID_CAP + 1) * sizeof(double));  // incl. the completion flag
+  memset(qp->h_scal, 0, (SL_COUNT + SCP_RESID_CAP + 2) * sizeof(double));  // incl. the completion flag
+  qp->h_persist = (unsigned*)(qp->h_scal + SL_COUNT + SCP_RESID_CAP + 1);  // status word of the persistent kernel
+  qp->h_persist_dev = (unsigned*)(qp->h_scal_dev + SL_COUNT + SCP_RESID_CAP + 1);
   // constant blocks (scp.py:10-28, :198-203, :227-232, :489-491), built on the host once per (K, h)
   const int Rf = qp->Rf;
   std::vector<double> F((size_t)Rf * K, 0.0), Ft((size_t)Rf * K, 0.0), S0((size_t)K * K, 0.0), S0t((size_t)K * K, 0.0),
@@ -856,6 +863,7 @@ extern "C" int scp_qp_reset(scp_qp* qp, const double* x0) {
   QP_CHECK(gemm(qp, qp->Rf, qp->K, 1.0, d.F, d.x, 0.0, d.zf));  // z = A x  (primal warm start, scp.py:443)
   SCP_HIP_CHECK(ctx, hipMemsetAsync(d.yf, 0, nf * sizeof(double), ctx->stream));
   qp->nW = 0;
+  qp->persist_cap_nW = -1;
   qp->rho = qp->st.rho;
   qp->cg1_ready = false;
   qp->csr_valid = false;
@@ -881,6 +889,7 @@ extern "C" int scp_qp_add_rows(scp_qp* qp, int64_t n, const int64_t* rows, const
                      qp->nW, n, rows, w_eta, w_l, d.HQ + nx, d.w_row, d.w_k, d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc);
   QP_LAUNCHED(qp);
   qp->nW += n;
+  qp->persist_cap_nW = -1;
   qp->cg1_ready = false;
   qp->csr_valid = false;
   qp->qx_fresh = false;  // HQ was scratch
@@ -901,17 +910,19 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
   int cg_total = 0, it = 0;
   double rp = INFINITY, rd = INFINITY;
   while (it < st.max_iter) {
-    // fixed rows only: every iteration up to the next termination check goes into ONE launch
+    // fixed rows only (everything is column-local), or the persistent single-step kernel: every iteration up to the
+    // next termination check goes into ONE launch
     const bool qp0_it = fused && qp->nW == 0;
+    const bool cg1_it = fused && st.cg_iters == 1 && qp->nW > 0;  // its update kernel emits delta-y itself
+    const bool persist_it = cg1_it && scp_qp_persist_eligible(qp);
     int n_it = 1;
-    if (qp0_it) {
+    if (qp0_it || persist_it) {
       n_it = st.check_termination - it % st.check_termination;
       if (it + n_it > st.max_iter) n_it = st.max_iter - it;
     }
     it += n_it;
     const bool will_check = it % st.check_termination == 0 || it >= st.max_iter;
     const bool with_dy = will_check && st.eps_prim_inf > 0.0;
-    const bool cg1_it = fused && st.cg_iters == 1 && qp->nW > 0;  // its update kernel emits delta-y itself
     if (with_dy && !cg1_it && !qp0_it) {  // snapshot of the duals: delta-y of this iteration feeds the certificate
       SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->d.dyf, qp->d.yf, (size_t)qp->Rf * qp->C * sizeof(double),
                                         hipMemcpyDeviceToDevice, ctx->stream));
@@ -919,13 +930,37 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
         SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->d.dyc, qp->d.yc, (size_t)qp->nW * sizeof(double),
                                           hipMemcpyDeviceToDevice, ctx->stream));
     }
-    if (cg1_it) QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total, with_dy));
-    else if (qp0_it) QP_CHECK(scp_qp_qp0_iterations(qp, n_it, with_dy ? qp->d.dyf : nullptr));
-    else if (fused) QP_CHECK(scp_qp_fused_iteration(qp, &cg_total));
-    else QP_CHECK(admm_iteration(qp, &cg_total));
+    bool persist_ran = false;
+    if (persist_it) {
+      int ran = 0;
+      QP_CHECK(scp_qp_cg1_persist(qp, n_it, with_dy, &ran));
+      persist_ran = ran != 0;
+      if (persist_ran) cg_total += n_it;
+    }
+    if (persist_ran) {
+      // (its completion status is read after the check below has drained the stream)
+    } else if (cg1_it) {
+      for (int j = 0; j < n_it; ++j) QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total, with_dy && j == n_it - 1));
+    } else if (qp0_it) {
+      QP_CHECK(scp_qp_qp0_iterations(qp, n_it, with_dy ? qp->d.dyf : nullptr));
+    } else if (fused) {
+      QP_CHECK(scp_qp_fused_iteration(qp, &cg_total));
+    } else {
+      QP_CHECK(admm_iteration(qp, &cg_total));
+    }
     if (will_check) {
       if (cg1_it || qp0_it) QP_CHECK(scp_qp_fused_residuals(qp, with_dy));
       else QP_CHECK(residuals(qp, with_dy));
+      if (persist_ran && *(volatile unsigned*)qp->h_persist != 1u) {
+        // The persistent launch gave up (its workgroups were not all resident at once, e.g. the device is shared with
+        // another stream's kernels): nothing was written back, so the iterations are repeated on the three-launch
+        // pipeline from the same state and this solver stays there.
+        qp->persist_off = true;
+        qp->persist_epoch = 0;
+        cg_total -= n_it;
+        for (int j = 0; j < n_it; ++j) QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total, with_dy && j == n_it - 1));
+        QP_CHECK(scp_qp_fused_residuals(qp, with_dy));
+      }
       if (!cg1_it) qp->cg1_ready = false;  // residuals() used G and the Q slabs as scratch (the fused check keeps
                                            // the pipeline's carried state and refreshes S0 x, F x exactly)
       const double* hs = qp->h_scal;
@@ -1001,6 +1036,7 @@ extern "C" int scp_qp_clone_state(scp_qp* dst, const scp_qp* src) {
   }
 #undef CP
   dst->nW = src->nW;
+  dst->persist_cap_nW = -1;
   dst->rho = src->rho;
   dst->st = src->st;
   dst->problem_set = true;
@@ -1038,5 +1074,33 @@ extern "C" int scp_qp_get_duals(scp_qp* qp, double* y_fixed, double* y_col) {
   }
   if (y_col && qp->nW > 0)
     SCP_HIP_CHECK(ctx, hipMemcpyAsync(y_col, qp->d.yc, qp->nW * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  return SCP_OK;
+}
+
+// test hook: copy one internal array of the solver to `out` (device pointer, capacity `cap` doubles); *n_out [host] = its
+// length.  names: "fx" (carried F x, [4K-1][C]), "qx" (carried S0 x, [K][C]), "gval" (row value per incidence entry),
+// "zf", "yf" ([4K-1][C]), "zc", "yc" (per working row), "x" ([K][C]).
+extern "C" int scp_qp_peek(scp_qp* qp, const char* name, double* out, int64_t cap, int64_t* n_out) {
+  if (!qp) return SCP_ERR_INVALID;
+  scp_ctx* ctx = qp->ctx;
+  SCP_REQUIRE(ctx, name && out && n_out, "qp_peek: null pointer");
+  const QpDev& d = qp->d;
+  const int64_t nf = (int64_t)qp->Rf * qp->C, nx = (int64_t)qp->K * qp->C;
+  const double* src = nullptr;
+  int64_t n = 0;
+  if (!strcmp(name, "fx")) { src = d.fx; n = nf; }
+  else if (!strcmp(name, "qx")) { src = qp->qx_sel ? d.HQ : d.HQ + nx; n = nx; }
+  else if (!strcmp(name, "gval")) { src = d.gval; n = 2 * qp->nW; }
+  else if (!strcmp(name, "zf")) { src = d.zf; n = nf; }
+  else if (!strcmp(name, "yf")) { src = d.yf; n = nf; }
+  else if (!strcmp(name, "zc")) { src = d.zc; n = qp->nW; }
+  else if (!strcmp(name, "yc")) { src = d.yc; n = qp->nW; }
+  else if (!strcmp(name, "x")) { src = d.x; n = nx; }
+  else if (!strcmp(name, "p")) { src = d.p; n = nx; }
+  else if (!strcmp(name, "qp")) { src = d.hpf; n = nx; }
+  else return scp_fail(ctx, SCP_ERR_INVALID, "qp_peek: unknown array %s", name);
+  *n_out = n;
+  if (n > cap) return scp_fail(ctx, SCP_ERR_CAPACITY, "qp_peek: %lld doubles needed", (long long)n);
+  if (n > 0) SCP_HIP_CHECK(ctx, hipMemcpyAsync(out, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   return SCP_OK;
 }

@@ -9,15 +9,13 @@
 // only where the algorithm needs the whole grid: the two PCG inner products and the row gather/scatter.
 // An ADMM step with n PCG steps is 4n + 3 launches, 7 at the default n = 1 (15n + ... on the generic path of scp_qp.hip, which stays as the fallback
 // for K > 128 and as the use_mfma = 0/2 reference); the arithmetic is the same, statement by statement.
-#include "scp_qp_internal.h"
+#include "scp_qp_device.h"
 #include <chrono>
-#include <mutex>
-#include <unordered_map>
 #include <cstdlib>
 
 namespace {
 
-constexpr int CB = 16;         // columns per workgroup
+using namespace scpdev;
 constexpr int FT = 1024;       // threads per workgroup (16 waves: one 16-row output tile per wave in most products)
 constexpr int NWV = FT / 64;
 
@@ -31,7 +29,6 @@ __device__ unsigned long long scp_phase_clk[64];
 #else
 #define PHASE_MARK(slot) ((void)0)
 #endif
-typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // O[R][16] = (ACC ? O : 0) + A[R][M] . V[M][16];  A: global, PACKED in operand order (QpDev::pF ...: [row tile][k step]
 // [lane], zero padded);  V, O: distinct LDS tiles.  The waves [w0, w0+nw) of the workgroup share the row tiles; other
@@ -455,84 +452,6 @@ __global__ __launch_bounds__(256) void fused_row_update_kernel(int64_t nW, int64
 //                       g = rho zc - yc - rho eta.dQx+ of the next right-hand side (gathered by cg1_col_kernel)
 // =====================================================================================================
 constexpr int SQ_BLOCKS = 128;
-constexpr int CHB = 16;  // operand registers (k steps) held at once by a tile product
-
-// Operands of the first CHB k-steps of row tile t of a packed matrix (wg_mm_range): fetched at kernel entry, long
-// before the vector they multiply exists.
-template <int CH>
-__device__ inline void tile_prefetch(const double* __restrict__ P, int nks, int t, int ks0, int ks1, double (&a)[CH]) {
-  const double* Ap = P + (size_t)t * nks * 64 + (threadIdx.x & 63);
-#pragma unroll
-  for (int s = 0; s < CH; ++s) a[s] = Ap[(size_t)min(ks0 + s, ks1 - 1) * 64];
-}
-
-// ---- wave-wide prefix sums over the time index (one wave per column, lane l holds the E consecutive steps
-// k = l E + e): the integrator blocks V, S, S0 and their transposes are first and second cumulative sums ------------
-// data-parallel-primitive moves (no LDS round trip, unlike __shfl): lanes without a source read 0
-template <int CTRL, int ROW_MASK>
-__device__ inline double dpp_mov0(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-// inclusive sum over the 64 lanes: row_shr 1, 2, 4, 8, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2, 3
-__device__ inline double wave_incl_sum(double v) {
-  v += dpp_mov0<0x111, 0xF>(v);
-  v += dpp_mov0<0x112, 0xF>(v);
-  v += dpp_mov0<0x114, 0xF>(v);
-  v += dpp_mov0<0x118, 0xF>(v);
-  v += dpp_mov0<0x142, 0xA>(v);
-  v += dpp_mov0<0x143, 0xC>(v);
-  return v;
-}
-// maximum of non-negative values over the 64 lanes, valid in lane 63
-__device__ inline double wave_max_nn(double v) {
-  v = fmax(v, dpp_mov0<0x111, 0xF>(v));
-  v = fmax(v, dpp_mov0<0x112, 0xF>(v));
-  v = fmax(v, dpp_mov0<0x114, 0xF>(v));
-  v = fmax(v, dpp_mov0<0x118, 0xF>(v));
-  v = fmax(v, dpp_mov0<0x142, 0xA>(v));
-  v = fmax(v, dpp_mov0<0x143, 0xC>(v));
-  return v;
-}
-__device__ inline double lane_below(double v) { return dpp_mov0<0x138, 0xF>(v); }  // wave_shr:1 (lane 0 <- 0)
-__device__ inline double lane_above(double v) { return dpp_mov0<0x130, 0xF>(v); }  // wave_shl:1 (lane 63 <- 0)
-
-// inclusive and exclusive prefix sums over the index i = lane E + e (ascending)
-template <int E>
-__device__ inline void wave_scan(const double (&v)[E], double (&incl)[E], double (&excl)[E]) {
-  double run = 0.0;
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    excl[e] = run;
-    run += v[e];
-    incl[e] = run;
-  }
-  const double off = lane_below(wave_incl_sum(run));  // total of the lower lanes
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    incl[e] += off;
-    excl[e] += off;
-  }
-}
-// value at index i - 1 / i + 1 (0 outside)
-template <int E>
-__device__ inline void wave_prev(const double (&v)[E], double (&o)[E]) {
-  o[0] = lane_below(v[E - 1]);
-#pragma unroll
-  for (int e = 1; e < E; ++e) o[e] = v[e - 1];
-}
-template <int E>
-__device__ inline void wave_next(const double (&v)[E], double (&o)[E]) {
-  o[E - 1] = lane_above(v[0]);
-#pragma unroll
-  for (int e = 0; e + 1 < E; ++e) o[e] = v[e + 1];
-}
-
-// per-column LDS rows are padded to a length = 2 (mod 32) doubles: the (column, time) accesses of the coalesced
-// global <-> LDS copies (16 columns x 2 steps per half wave) and of the MFMA operand reads then hit 32 distinct banks
-__host__ __device__ inline int pad_col(int n) { return ((n + 29) / 32) * 32 + 2; }
-
 // Column kernel of the single-step pipeline (launch 1 of 3).  With F x carried like S0 x,
 //   r = sigma x + A^T(rho z - y) - H x = -2 x + F^T W' + S0^T G,   W' = rho w (z_f - F x) - y_f,
 // (H_f = (2 + sigma) I + rho F^T w F), then p = H_f^{-1} r, S0 p, F p.  F = [J ; I ; V ; S] and S0 are the jerk
@@ -578,8 +497,8 @@ __global__ __launch_bounds__(FT) void cg1_col_kernel(int K, int Rf, int64_t C, d
     double acc = 0.0;
     xv = 0.0;
     if (cok && k < K) {
-      g0 = cell_ptr[k * N + agent];
-      g1 = cell_ptr[k * N + agent + 1];
+      g0 = cell_ptr[cell_of(k, agent, K)];
+      g1 = cell_ptr[cell_of(k, agent, K) + 1];
       xv = x[(int64_t)k * C + c0 + c];
     }
     for (int t = g0; t < g1; ++t) acc += coef[(size_t)t * D + dd] * gval[t];
@@ -588,8 +507,8 @@ __global__ __launch_bounds__(FT) void cg1_col_kernel(int K, int Rf, int64_t C, d
   int g0 = 0, g1 = 0;
   double xv0 = 0.0;
   if (cok && kg < K) {
-    g0 = cell_ptr[kg * N + agent];
-    g1 = cell_ptr[kg * N + agent + 1];
+    g0 = cell_ptr[cell_of(kg, agent, K)];
+    g1 = cell_ptr[cell_of(kg, agent, K) + 1];
     xv0 = x[(int64_t)kg * C + c0 + c];
   }
   double wz[WU], wf[WU], wy[WU];
@@ -1095,20 +1014,11 @@ __global__ __launch_bounds__(256) void cg1_rows_init_kernel(int64_t nW, int64_t 
 
 #define FUSED_LAUNCHED(qp) SCP_HIP_CHECK((qp)->ctx, hipGetLastError())
 
-// Tiles beyond 64 KiB of dynamic LDS (K > 50) need the limit raised once per kernel (gfx950: 160 KiB per workgroup).
+// Tiles beyond 64 KiB of dynamic LDS (K > 50) need the limit raised per (device, kernel): scp_raise_lds_limit.
 template <typename Kern>
 int allow_lds(scp_qp* qp, Kern kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return SCP_OK;
-  // the attribute belongs to the kernel, not to the launch: raised once per kernel (and again only for a larger
-  // request) instead of on every iteration
-  static std::mutex mu;
-  static std::unordered_map<const void*, size_t> allowed;
-  const void* key = reinterpret_cast<const void*>(kernel);
-  std::lock_guard<std::mutex> lock(mu);
-  size_t& have = allowed[key];
-  if (have >= bytes) return SCP_OK;
-  SCP_HIP_CHECK(qp->ctx, hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  have = bytes;
+  SCP_HIP_CHECK(qp->ctx, scp_raise_lds_limit(qp->ctx->device, reinterpret_cast<const void*>(kernel), bytes));
   return SCP_OK;
 }
 
@@ -1325,13 +1235,13 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count, bool emit_dy) {
 // =====================================================================================================
 namespace {
 
-__global__ __launch_bounds__(256) void csr_count_kernel(int64_t nW, int N, const int* __restrict__ wk,
+__global__ __launch_bounds__(256) void csr_count_kernel(int64_t nW, int K, const int* __restrict__ wk,
                                                          const int* __restrict__ wi, const int* __restrict__ wj,
                                                          int* __restrict__ cnt) {
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= nW) return;
-  atomicAdd(cnt + wk[n] * N + wi[n], 1);  // integer counts: order independent
-  atomicAdd(cnt + wk[n] * N + wj[n], 1);
+  atomicAdd(cnt + cell_of(wk[n], wi[n], K), 1);  // integer counts: order independent
+  atomicAdd(cnt + cell_of(wk[n], wj[n], K), 1);
 }
 
 // exclusive scan of cnt[0..ncell) into ptr (in place: cnt and ptr are the same array), cursors = ptr; one workgroup,
@@ -1385,13 +1295,13 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int ncell, int* __restri
   if (threadIdx.x == 0) ptr[ncell] = carry_s;
 }
 
-__global__ __launch_bounds__(256) void csr_fill_kernel(int64_t nW, int N, const int* __restrict__ wk,
+__global__ __launch_bounds__(256) void csr_fill_kernel(int64_t nW, int K, const int* __restrict__ wk,
                                                         const int* __restrict__ wi, const int* __restrict__ wj,
                                                         int* __restrict__ cur, int* __restrict__ ent) {
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= nW) return;
-  ent[atomicAdd(cur + wk[n] * N + wi[n], 1)] = (int)(2 * n);
-  ent[atomicAdd(cur + wk[n] * N + wj[n], 1)] = (int)(2 * n + 1);
+  ent[atomicAdd(cur + cell_of(wk[n], wi[n], K), 1)] = (int)(2 * n);
+  ent[atomicAdd(cur + cell_of(wk[n], wj[n], K), 1)] = (int)(2 * n + 1);
 }
 
 // entries of a cell arrive in atomic order: sort them (ascending code) so that every sum has a fixed order
@@ -1449,7 +1359,7 @@ __global__ __launch_bounds__(256) void csr_gather_kernel(int K, int N, int D, co
   if (t >= C * K) return;
   const int k = (int)(t / C), col = (int)(t % C);
   const int agent = col / D, d = col - agent * D;
-  const int cell = k * N + agent;
+  const int cell = cell_of(k, agent, K);
   double acc = 0.0;
   const int t1 = ptr[cell + 1];
   for (int e = ptr[cell]; e < t1; ++e) acc += coef[(size_t)e * D + d] * gval[e];
@@ -1466,9 +1376,9 @@ int scp_qp_csr_build(scp_qp* qp) {
   SCP_HIP_CHECK(qp->ctx, hipMemsetAsync(d.cell_ptr, 0, (size_t)(ncell + 1) * sizeof(int), s));
   if (qp->nW > 0) {
     const dim3 rgrid((unsigned)((qp->nW + 255) / 256));
-    hipLaunchKernelGGL(csr_count_kernel, rgrid, dim3(256), 0, s, qp->nW, qp->N, d.w_k, d.w_i, d.w_j, d.cell_ptr);
+    hipLaunchKernelGGL(csr_count_kernel, rgrid, dim3(256), 0, s, qp->nW, qp->K, d.w_k, d.w_i, d.w_j, d.cell_ptr);
     hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, ncell, d.cell_ptr, d.cell_cur);
-    hipLaunchKernelGGL(csr_fill_kernel, rgrid, dim3(256), 0, s, qp->nW, qp->N, d.w_k, d.w_i, d.w_j, d.cell_cur, d.ent_code);
+    hipLaunchKernelGGL(csr_fill_kernel, rgrid, dim3(256), 0, s, qp->nW, qp->K, d.w_k, d.w_i, d.w_j, d.cell_cur, d.ent_code);
     hipLaunchKernelGGL(csr_sort_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, ncell, d.cell_ptr, d.ent_code);
     hipLaunchKernelGGL(csr_finish_kernel, dim3((unsigned)((2 * qp->nW + 255) / 256)), dim3(256), 0, s, 2 * qp->nW, qp->D,
                        d.ent_code, d.w_eta, d.coef, d.pos_i, d.pos_j);
@@ -1620,7 +1530,7 @@ __global__ __launch_bounds__(FT) void cg1_resid_col_kernel(int K, int Rf, int64_
     double acc = 0.0, acc2 = 0.0, xv = 0.0;
     if (cok) {
       if (has_rows) {
-        const int cell = k * N + agent;
+        const int cell = cell_of(k, agent, K);
         const int t0 = cell_ptr[cell], t1 = cell_ptr[cell + 1];
         for (int t = t0; t < t1; ++t) acc += coef[(size_t)t * D + dd_] * gval[t];
         if (with_dy)

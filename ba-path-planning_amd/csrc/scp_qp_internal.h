@@ -44,6 +44,7 @@ struct QpDev {
   double* gval2;  // [2 cap]   row vectors of a termination check: yc ...
   double* gval3;  // [2 cap]   ... and delta-yc (gval keeps the pipeline's values across a check)
   int *pos_i, *pos_j;  // [cap] entry positions of row n
+  unsigned long long* sync_words;  // SCP_SYNC_WORDS: arrival counters + give-up word of the persistent kernel, scratch
 };
 
 struct scp_qp {
@@ -63,6 +64,13 @@ struct scp_qp {
   double* h_scal;  // pinned, SL_COUNT + SCP_RESID_CAP doubles + the completion flag of a fused check
   double* h_scal_dev;  // the same memory as the device sees it: the check kernels write their partials straight to it
   unsigned long long check_seq;  // value the flag takes when the current check has finished
+  // persistent single-step kernel (scp_qp_persist.hip)
+  bool persist_off;                  // a launch gave up (workgroups not co-resident): stay on the three-launch pipeline
+  int64_t persist_cap_nW;            // working-set size the entry capacity below was measured for (-1: none)
+  int persist_cap;                   // LDS entry capacity per workgroup = most entries around any block of agents
+  unsigned long long persist_epoch;  // rendezvous completed by every workgroup so far (counters are never reset)
+  unsigned* h_persist;               // mapped host word written by the kernel: 1 done, 2 gave up
+  unsigned* h_persist_dev;
 };
 
 
@@ -82,6 +90,10 @@ int scp_qp_qp0_iterations(scp_qp* qp, int nit, double* dy_out);
 // 2: g = vec[n].  Two launches, no atomics.
 int scp_qp_csr_scatter(scp_qp* qp, int mode, const double* vec);
 int scp_qp_csr_build(scp_qp* qp);
+int scp_qp_cg1_prepare(scp_qp* qp);
+constexpr int SCP_SYNC_WORDS = 3 * 128;  // u64: 8 counters on lines of their own | give-up word | scratch
+bool scp_qp_persist_eligible(const scp_qp* qp);
+int scp_qp_cg1_persist(scp_qp* qp, int nit, bool emit_dy, int* ran);
 // (re)pack F, Ft, S0, S0t, HS, Minv into the MFMA operand order; called at the end of build_kkt
 int scp_qp_pack_operands(scp_qp* qp);
 static inline size_t scp_packed_count(int R, int M) { return (size_t)((R + 15) / 16) * ((M + 3) / 4) * 64; }

@@ -35,7 +35,7 @@ class QpSettings(C.Structure):
         ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("max_iter", C.c_int32),
         ("check_termination", C.c_int32), ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32),
         ("adaptive_rho_tolerance", C.c_double), ("cg_iters", C.c_int32), ("use_mfma", C.c_int32),
-        ("rho_col_scale", C.c_double), ("eps_prim_inf", C.c_double),
+        ("rho_col_scale", C.c_double), ("eps_prim_inf", C.c_double), ("persistent", C.c_int32),
     ]
 
 
@@ -61,7 +61,7 @@ EXPORTS = [
     "scp_collision_violations", "scp_gather_rows", "scp_rel_step", "scp_qp_default_settings",
     "scp_qp_workspace_bytes", "scp_qp_create", "scp_qp_destroy", "scp_qp_update_settings", "scp_qp_set_problem",
     "scp_qp_reset", "scp_qp_add_rows", "scp_qp_solve", "scp_qp_clone_state", "scp_qp_get_solution",
-    "scp_qp_get_duals", "scp_gemm_f64",
+    "scp_qp_get_duals", "scp_gemm_f64", "scp_qp_peek",
 ]
 
 
@@ -116,6 +116,7 @@ def load_library():
     lib.scp_qp_get_solution.argtypes = [vp, vp]
     lib.scp_qp_get_duals.argtypes = [vp, vp, vp]
     lib.scp_gemm_f64.argtypes = [vp, i32, i32, i32, i32, f64, vp, vp, f64, vp]
+    lib.scp_qp_peek.argtypes = [vp, C.c_char_p, vp, i64, C.POINTER(i64)]
     _LIB, _LIB_PATH = lib, path
     return lib
 
@@ -381,6 +382,14 @@ class QP:
         x = self.ctx.empty(self.N, self.K, self.D)
         self.ctx.check(self.ctx.lib.scp_qp_get_solution(self.h_qp, x.data_ptr()))
         return x
+
+    def peek(self, name):
+        """internal array `name` of the solver (test hook, see scp_qp_peek)"""
+        cap = (4 * self.K - 1) * self.N * self.D + 2 * max(self.n_rows, 1)
+        out = self.ctx.empty(cap)
+        n = C.c_int64()
+        self.ctx.check(self.ctx.lib.scp_qp_peek(self.h_qp, name.encode(), out.data_ptr(), cap, C.byref(n)))
+        return out[: n.value]
 
     def duals(self):
         yf = self.ctx.empty(self.N * self.D * (4 * self.K - 1))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SCP_ABI_VERSION 1
+#define SCP_ABI_VERSION 2
 
 typedef enum scp_status {
   SCP_OK = 0,
@@ -64,7 +64,7 @@ typedef struct scp_qp_settings {
   int32_t adaptive_rho;          /* 1 */
   int32_t adaptive_rho_interval; /* 25 (iterations; multiple of check_termination) */
   double adaptive_rho_tolerance; /* 5 */
-  int32_t cg_iters;              /* 1: PCG steps per ADMM step (fixed count, warm started at x) */
+  int32_t cg_iters;              /* 1: PCG steps per ADMM step (fixed count >= 1, warm started at x) */
   int32_t use_mfma;              /* 1: fused column-block kernels, every K-dimension product on
                                     v_mfma_f64_16x16x4_f64 (K <= 120; larger K falls back to 2);
                                     2: one MFMA product per launch (generic path); 0: VALU products */
@@ -73,6 +73,10 @@ typedef struct scp_qp_settings {
                                     the same SCP iterates with 3.5 x fewer ADMM iterations than scale 1 */
   double eps_prim_inf;           /* 1e-4: OSQP's primal infeasibility tolerance; the certificate (delta-y test) is
                                     evaluated at every termination check; <= 0 disables it */
+  int32_t persistent;            /* 1: cg_iters == 1, K <= 64 and at most one block of 16/D agents per compute unit run
+                                    all ADMM steps between two termination checks in ONE persistent launch (solver state
+                                    on chip, two grid-wide exchanges per step); 0: three launches per step.  Same
+                                    arithmetic up to the summation order of the line-search partials */
 } scp_qp_settings;
 
 /* [host] result of scp_qp_solve */
@@ -187,6 +191,11 @@ int scp_qp_get_duals(scp_qp* qp, double* y_fixed, double* y_col);
  * Y[R][C] = alpha * A[R][M] X[M][C] + beta * Y, row-major, device pointers. */
 int scp_gemm_f64(scp_ctx* ctx, int use_mfma, int R, int M, int C, double alpha, const double* A,
                  const double* X, double beta, double* Y);
+/* Copy one internal array of the solver (time-major device layout) to `out` (device, capacity `cap` doubles);
+ * *n_out [host] = its length.  name: "x" [K][C], "zf" / "yf" / "fx" [4K-1][C] (fx = carried F x), "qx" [K][C] (carried S0 x),
+ * "zc" / "yc" per working row, "gval" per incidence-list entry.  tests/test_qp_gpu.py compares the state the persistent
+ * and the three-launch pipelines leave behind. */
+int scp_qp_peek(scp_qp* qp, const char* name, double* out, int64_t cap, int64_t* n_out);
 
 #ifdef __cplusplus
 }

@@ -27,9 +27,20 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_hip.EXPORTS), declared ^ set(_hip.EXPORTS)
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert lib.scp_abi_version() == 1
+    assert lib.scp_abi_version() == 2
     # struct layouts agree with the header
-    assert ctypes.sizeof(_hip.QpSettings) == 96 and ctypes.sizeof(_hip.QpInfo) == 56  # == sizeof in C (checked with g++)
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:  # sizeof as the C compiler sees the header
+        src = os.path.join(tmp, "sz.c")
+        with open(src, "w") as f:
+            f.write('#include <stdio.h>\n#include "scp_hip.h"\nint main(void){printf("%zu %zu %zu", sizeof(scp_qp_settings), '
+                    'sizeof(scp_qp_info), sizeof(scp_pair_stats));return 0;}\n')
+        exe = os.path.join(tmp, "sz")
+        subprocess.run(["gcc", "-I", os.path.dirname(HEADER), src, "-o", exe], check=True)
+        sizes = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    assert [ctypes.sizeof(_hip.QpSettings), ctypes.sizeof(_hip.QpInfo), 32] == sizes, sizes
     s = _hip.default_settings()
     assert (s.rho, s.sigma, s.alpha, s.eps_abs, s.eps_rel, s.max_iter, s.check_termination) == (
         0.1, 1e-6, 1.6, 1e-3, 1e-3, 4000, 25)  # OSQP defaults

@@ -21,10 +21,11 @@ pos, _ = so.kinematics(prob, x0)
 eta, l, dist = so.linearize_pairs(prob, pos)
 W = np.nonzero(dist - prob.R < 0.5)[0]
 ctx = _hip.Context(0)
-for cap in (5, 25, 50, 100, 300):
+persist = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+for cap in (1, 2, 5, 25, 50, 100, 300):
     st = qo.Settings(max_iter=cap, max_rounds=1, check_termination=10 ** 6, adaptive_rho=False, cg_iters=cg)
     xo, yo, io = qo.admm_structured(prob, eta, l, dist, x0=x0, st=st, rows0=W)
-    hs = _hip.default_settings(max_iter=cap, check_termination=10 ** 6, adaptive_rho=0, cg_iters=cg)
+    hs = _hip.default_settings(max_iter=cap, check_termination=10 ** 6, adaptive_rho=0, cg_iters=cg, persistent=persist)
     qp = _hip.QP(ctx, prob.N, prob.K, 2, prob.h, hs)
     qp.set_problem([-2, 2, -15, 15, -20, 20], [0, 0, 20, 20], ctx.tensor(prob.p0), ctx.tensor(prob.v0), ctx.tensor(prob.pf),
                    ctx.tensor(prob.vf))

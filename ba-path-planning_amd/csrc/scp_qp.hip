@@ -511,6 +511,8 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.pos_i = c.take<int>((size_t)cap);
   d.pos_j = c.take<int>((size_t)cap);
   d.sync_words = c.take<unsigned long long>(SCP_SYNC_WORDS);
+  d.cells = c.take<unsigned long long>((size_t)2 * nx);
+  d.gpart = c.take<unsigned long long>(SCP_GPART_WORDS);
   return c.off;
 }
 

@@ -44,7 +44,9 @@ struct QpDev {
   double* gval2;  // [2 cap]   row vectors of a termination check: yc ...
   double* gval3;  // [2 cap]   ... and delta-yc (gval keeps the pipeline's values across a check)
   int *pos_i, *pos_j;  // [cap] entry positions of row n
-  unsigned long long* sync_words;  // SCP_SYNC_WORDS: arrival counters + give-up word of the persistent kernel, scratch
+  unsigned long long* sync_words;  // SCP_SYNC_WORDS: give-up word of the persistent kernel, scratch
+  unsigned long long* cells;       // [K][N][D][2] tagged granules: S0 p cells published by the persistent kernel
+  unsigned long long* gpart;       // SCP_GPART_WORDS tagged granules: line-search partials, two alternating buffers
 };
 
 struct scp_qp {
@@ -68,7 +70,7 @@ struct scp_qp {
   bool persist_off;                  // a launch gave up (workgroups not co-resident): stay on the three-launch pipeline
   int64_t persist_cap_nW;            // working-set size the entry capacity below was measured for (-1: none)
   int persist_cap;                   // LDS entry capacity per workgroup = most entries around any block of agents
-  unsigned long long persist_epoch;  // rendezvous completed by every workgroup so far (counters are never reset)
+  unsigned long long persist_epoch;  // ADMM steps run by persistent launches so far: the step tags of the granules never repeat
   unsigned* h_persist;               // mapped host word written by the kernel: 1 done, 2 gave up
   unsigned* h_persist_dev;
 };
@@ -91,7 +93,8 @@ int scp_qp_qp0_iterations(scp_qp* qp, int nit, double* dy_out);
 int scp_qp_csr_scatter(scp_qp* qp, int mode, const double* vec);
 int scp_qp_csr_build(scp_qp* qp);
 int scp_qp_cg1_prepare(scp_qp* qp);
-constexpr int SCP_SYNC_WORDS = 3 * 128;  // u64: 8 counters on lines of their own | give-up word | scratch
+constexpr int SCP_SYNC_WORDS = 16;  // u64: give-up word | scratch
+constexpr int SCP_GPART_WORDS = 2 * 256 * 4;  // two buffers x (at most one workgroup per CU) x two doubles as granule pairs
 bool scp_qp_persist_eligible(const scp_qp* qp);
 int scp_qp_cg1_persist(scp_qp* qp, int nit, bool emit_dy, int* ran);
 // (re)pack F, Ft, S0, S0t, HS, Minv into the MFMA operand order; called at the end of build_kkt

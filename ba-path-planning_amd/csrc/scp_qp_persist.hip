@@ -12,11 +12,15 @@
 //   * every working row (k, i, j) is REPLICATED in the workgroups that own agent i and agent j (entries of the
 //     agent-major incidence lists, kept in LDS): both copies run the same instructions on the same values, so z_c, y_c
 //     and the row value g evolve bit-identically on both sides and A_W^T g needs no exchange at all;
-//   * what crosses workgroups per step is (1) the S0 p cells of the partner agent and (2) the two scalars of the exact
-//     line search  a = r.p / (r.p + rho_c sum (eta . d S0 p)^2) : two grid-wide exchanges, each a write-through publish,
-//     a sharded arrival counter and relaxed agent-scope polls -- no release / acquire fences (MI355X_MICROARCH.md,
-//     inter-workgroup visibility, "valid forms" row 1; measured 1.5 us for the barrier alone, 2.5 us with an all-reduce,
-//     tools/grid_sync_bench.hip) against 3 kernel boundaries + 3 cold prologues (21.6 us per step in round 1).
+//   * what crosses workgroups per step is (1) the S0 p cells of the partner agents -- a neighbour-only hand-off -- and
+//     (2) the two scalars of the exact line search  a = r.p / (r.p + rho_c sum (eta . d S0 p)^2), an all-gather of two
+//     doubles per workgroup.  Both travel as DATA-TAGGED GRANULES (MI355X_MICROARCH.md, hand-off form R2): every 8-byte
+//     word is {step tag, 32 payload bits}, written by one write-through (agent-scope relaxed atomic) store and polled by
+//     agent-scope loads until its tag is the current step.  The data is the flag: no counters, no fences, no grid
+//     barrier (measured with counters + barrier: 4.4 + 2.8 us of a 13 us step; profiles/r02_phase_profile_*.txt).
+//     Reuse of a buffer is safe because the all-gather is a full dependency of every step: a workgroup republishes its
+//     S0 p cells only after it has every partial of the previous step, which every workgroup publishes after reading
+//     its partners' cells; the partials alternate between two buffers.
 // Every spin is bounded: a workgroup that times out raises a give-up word, every workgroup then leaves WITHOUT writing
 // state back, and the host repeats the iterations on the three-launch pipeline.
 #include "scp_qp_device.h"
@@ -25,9 +29,21 @@ namespace {
 using namespace scpdev;
 
 typedef unsigned long long u64;
-constexpr int NSHARD = 8;             // arrival counters (workgroup b adds to shard b % 8), one 128-byte line each
-constexpr int SHARD_STRIDE = 16;      // u64 per shard
-constexpr unsigned SPIN_LIMIT = 1u << 21;
+constexpr unsigned SPIN_LIMIT = 1u << 20;
+
+// Developer build (make prof): 100 MHz wall-clock ticks spent per phase, summed over the steps of one launch, middle
+// workgroup, thread 0.
+#ifdef SCP_PHASE_PROFILE
+__device__ unsigned long long scp_persist_clk[16];
+#define PSTAMP(slot)                                  \
+  do {                                                \
+    const unsigned long long now_ = wall_clock64();   \
+    pacc[slot] += now_ - plast;                       \
+    plast = now_;                                     \
+  } while (0)
+#else
+#define PSTAMP(slot) ((void)0)
+#endif
 
 struct PersistArgs {
   int K, N, nblk, nit, emit_dy, ent_cap;
@@ -36,66 +52,30 @@ struct PersistArgs {
   const double* pMinv;
   const double *lf, *uf;
   double *zf, *yf, *fx, *x, *Qx, *dyf;
-  double* Qp_pub;   // [K][C] exchange slab: S0 p of every column
-  double* part;     // [2 parities][rz | sq][nblk * waves] per-wave partials of the line search
-  u64* shards;
+  u64* cells;       // [K][N][D][2] granules: S0 p of (time step, agent), low / high word, each tagged with the step
+  u64* gpart;       // [2 parities][nblk][4] granules: r.p and sum (eta . d S0 p)^2 of one workgroup
   unsigned* give_up;
   const int *cell_ptr, *ent_code, *w_k, *w_i, *w_j;
   const double *w_eta, *w_l;
   double *zc, *yc, *dyc, *gval;
   unsigned* host_status;  // mapped host word: 1 = all steps done, 2 = gave up
-  u64 epoch0;             // arrivals per workgroup before this launch (the counters are never reset between launches)
+  unsigned epoch0;        // steps completed by earlier launches (tags never repeat; the buffers start zeroed)
 };
 
-__device__ inline void st_agent(double* p, double v) {
-  __hip_atomic_store((u64*)p, (u64)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ inline void st_granules(u64* g, unsigned tag, double v) {
+  const u64 t = (u64)tag << 32;
+  __hip_atomic_store(g, t | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(g + 1, t | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ inline double ld_agent(const double* p) {
-  return __longlong_as_double((long long)__hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-
-// Grid-wide rendezvous after a write-through publish: every storing wave drains its stores, one lane adds to the
-// workgroup's shard, wave 0 polls all shards (relaxed, agent scope).  Returns false when the spin limit was hit or
-// another workgroup gave up.
-__device__ inline bool grid_rendezvous(u64* shards, int nblk, u64 epoch, unsigned* give_up, int* ok_s) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(shards + (blockIdx.x % NSHARD) * SHARD_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *ok_s = 1;
-  }
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
-    const u64 per = lane < NSHARD ? (u64)((nblk - lane + NSHARD - 1) / NSHARD) : 0ull;
-    const u64 target = per * epoch;
-    unsigned spins = 0;
-    bool ok = true;
-    for (;;) {
-      u64 v = target;
-      if (lane < NSHARD) v = __hip_atomic_load(shards + lane * SHARD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__all(v >= target)) break;
-      if (++spins > SPIN_LIMIT || __hip_atomic_load(give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-        ok = false;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (!ok && lane == 0) {
-      __hip_atomic_store(give_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *ok_s = 0;
-    }
-  }
-  __syncthreads();
-  return *ok_s != 0;
-}
+__device__ inline u64 ld_granule(const u64* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <int D>
 __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs A) {
   constexpr int APB = CB / D;    // agents = waves per workgroup
   constexpr int NT = 64 * APB;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  __shared__ double red_rz[APB], red_sq[APB];
-  __shared__ int ok_s;
+  __shared__ double red[2][APB];
+  __shared__ int fail_s;
   const int K = A.K, N = A.N;
   const int64_t C = A.C;
   const int RSK = pad_col(K);
@@ -103,7 +83,8 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
   double* Rt = lds;                        // [16][RSK]   r, MFMA B operand
   double* Pt = Rt + CB * RSK;              // [16][RSK]   p
   double* Qt = Pt + CB * RSK;              // [APB][64][D] own S0 p cells
-  double* e_c = Qt + APB * 64 * D;         // [cap][D] signed eta (+ on agent i's side, - on agent j's)
+  double* gp = Qt + APB * 64 * D;          // [nblk][2]   all-gathered partials (r.p, row term)
+  double* e_c = gp + 2 * A.nblk;           // [cap][D] signed eta (+ on agent i's side, - on agent j's)
   double* e_l = e_c + (size_t)cap * D;     // [cap] lower bound
   double* e_z = e_l + cap;                 // [cap]
   double* e_y = e_z + cap;                 // [cap]
@@ -112,7 +93,7 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
   double* e_qp = e_qo + (size_t)cap * D;   // [cap][D] S0 x cell of the partner agent
   double* e_pp = e_qp + (size_t)cap * D;   // [cap][D] S0 p cell of the partner agent (this step)
   int* e_code = (int*)(e_pp + (size_t)cap * D);  // [cap] k | local agent << 8 | side << 16
-  int* e_pad = e_code + cap;               // [cap] index of the partner's cell in the [K][C] slabs
+  int* e_pad = e_code + cap;               // [cap] granule index of the partner's cell
   int* e_row = e_pad + cap;                // [cap] working row n
   int* cptr = e_row + cap;                 // [APB K + 1] cell offsets relative to this workgroup's first entry
 
@@ -124,7 +105,7 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
   const bool live = aok && k < K;
   const double h = A.h, hh = h * h, rho = A.rho, rho_c = A.rho_c, alpha = A.alpha;
   const int tK = (K + 15) >> 4, nks = (K + 3) >> 2;
-  const int nparts = A.nblk * APB;
+  const int nblk = A.nblk;
 
   // ---- entries of this block of agents (contiguous in the agent-major incidence lists) --------------------------
   const int a1 = min(a0 + APB, N);
@@ -137,6 +118,7 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
     }
     return;
   }
+  if (threadIdx.x == 0) fail_s = 0;
   for (int i = threadIdx.x; i <= (a1 - a0) * K; i += NT) cptr[i] = A.cell_ptr[cell_of(0, a0, K) + i] - ebase;
   for (int e = threadIdx.x; e < ne; e += NT) {
     const int code = A.ent_code[ebase + e];
@@ -144,15 +126,15 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
     const int wi = A.w_i[n], wj = A.w_j[n], wk = A.w_k[n];
     const int own = side ? wj : wi, par = side ? wi : wj;
     e_code[e] = wk | ((own - a0) << 8) | (side << 16);
-    e_pad[e] = (int)((int64_t)wk * C + (int64_t)par * D);
+    e_pad[e] = ((wk * N + par) * D) * 2;
     e_row[e] = n;
-    const int64_t bo = (int64_t)wk * C + (int64_t)own * D;
+    const int64_t bo = (int64_t)wk * C + (int64_t)own * D, bp = (int64_t)wk * C + (int64_t)par * D;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const double eta = A.w_eta[(size_t)n * D + d];
       e_c[(size_t)e * D + d] = side ? -eta : eta;
       e_qo[(size_t)e * D + d] = A.Qx[bo + d];
-      e_qp[(size_t)e * D + d] = A.Qx[e_pad[e] + d];
+      e_qp[(size_t)e * D + d] = A.Qx[bp + d];
     }
     e_l[e] = A.w_l[n];
     e_z[e] = A.zc[n];
@@ -190,38 +172,49 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
   double aM[CHB];
   tile_prefetch<CHB>(A.pMinv, nks, wave < tK ? wave : 0, 0, nks, aM);
   __syncthreads();
+  // incidence-list range of this lane's cell (time step k of this wave's agent); cells without entries publish nothing
+  const int c0 = aok ? cptr[wave * K + min(k, K - 1)] : 0;
+  const int c1 = (aok && k < K) ? cptr[wave * K + k + 1] : c0;
+  u64* my_cell = A.cells + ((size_t)((int64_t)min(k, K - 1) * N + (aok ? agent : 0)) * D) * 2;
 
-  u64 epoch = A.epoch0;
+#ifdef SCP_PHASE_PROFILE
+  unsigned long long pacc[16] = {0}, plast = wall_clock64();
+#endif
+  PSTAMP(0);
   bool ok = true;
   double dy[D][4];
   for (int it = 0; it < A.nit; ++it) {
-    const int par = it & 1;
-    double* part_rz = A.part + (size_t)(2 * par) * nparts;
-    double* part_sq = A.part + (size_t)(2 * par + 1) * nparts;
+    const unsigned tag = A.epoch0 + (unsigned)it + 1u;
+    u64* gpart = A.gpart + (size_t)(tag & 1u) * nblk * 4;
     // ---- r = -2 x + F^T W' + S0^T G: reverse cumulative sums as suffix scans over the lanes ------------------------
     double r[D];
     {
-      const int c0 = aok ? cptr[wave * K + min(k, K - 1)] : 0;
-      const int c1 = (aok && k < K) ? cptr[wave * K + k + 1] : c0;
+      double g[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) g[d] = 0.0;
+      for (int e = c0; e < c1; ++e) {
+        const double ge = e_g[e];
+#pragma unroll
+        for (int d = 0; d < D; ++d) g[d] += e_c[(size_t)e * D + d] * ge;
+      }
 #pragma unroll
       for (int d = 0; d < D; ++d) {
-        double g = 0.0;
-        for (int e = c0; e < c1; ++e) g += e_c[(size_t)e * D + d] * e_g[e];
         const double wj = rr[0] * (z[d][0] - fx[d][0]) - y[d][0];
         const double wa = rr[1] * (z[d][1] - fx[d][1]) - y[d][1];
         const double wv = rr[2] * (z[d][2] - fx[d][2]) - y[d][2];
         const double wp = rr[3] * (z[d][3] - fx[d][3]) - y[d][3];
-        const double u1 = h * wv + 0.5 * hh * (wp - g);
-        const double u2 = wp + g;
+        const double u1 = h * wv + 0.5 * hh * (wp - g[d]);
+        const double u2 = wp + g[d];
         const double d1 = wave_incl_rsum(u1);
         const double s1 = wave_incl_rsum(u2);
         const double d2 = lane_above(wave_incl_rsum(s1));  // exclusive suffix sum
         const double wjm = lane_below(wj);                  // w_j[k - 1]
-        r[d] = (((wjm - wj) / h + wa) + (d1 + 0.5 * hh * g) + hh * d2) - 2.0 * x[d];
+        r[d] = (((wjm - wj) / h + wa) + (d1 + 0.5 * hh * g[d]) + hh * d2) - 2.0 * x[d];
         if (live) Rt[(wave * D + d) * RSK + k] = r[d];
       }
     }
     __syncthreads();
+    PSTAMP(1);
     // ---- p = H_f^{-1} r on the matrix cores: one 16-row tile per wave --------------------------------------------
     if (wave < tK) {
       const int li = lane & 15, lk = lane >> 4;
@@ -241,72 +234,125 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
       }
     }
     __syncthreads();
-    // ---- S0 p, F p (forward scans), r.p; publish the S0 p cells --------------------------------------------------------
+    PSTAMP(2);
+    // ---- S0 p, F p (forward scans), r.p; publish the S0 p cells that have rows -----------------------------------------
     double p[D], qp[D], fp[D][4];
     double rz = 0.0;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       p[d] = live ? Pt[(wave * D + d) * RSK + k] : 0.0;
       rz += (live ? r[d] : 0.0) * p[d];
-      const double c1 = wave_incl_sum(p[d]);
-      const double c2 = lane_below(wave_incl_sum(c1));
-      const double c1p = lane_below(c1);
+      const double cs1 = wave_incl_sum(p[d]);
+      const double cs2 = lane_below(wave_incl_sum(cs1));
+      const double cs1p = lane_below(cs1);
       const double pn = lane_above(p[d]);
-      qp[d] = hh * (c2 - 0.5 * c1p);
+      qp[d] = hh * (cs2 - 0.5 * cs1p);
       fp[d][0] = (live && k < K - 1) ? (pn - p[d]) / h : 0.0;
       fp[d][1] = p[d];
-      fp[d][2] = live ? h * c1 : 0.0;  // lanes beyond the horizon hold the running totals: keep their rows at zero,
-      fp[d][3] = live ? hh * (c2 + 0.5 * c1) : 0.0;  // or the next step's suffix sums would pick them up
-      if (live) {
+      fp[d][2] = live ? h * cs1 : 0.0;  // lanes beyond the horizon hold the running totals: keep their rows at zero,
+      fp[d][3] = live ? hh * (cs2 + 0.5 * cs1) : 0.0;  // or the next step's suffix sums would pick them up
+      if (c1 > c0) {
+        st_granules(my_cell + 2 * d, tag, qp[d]);
         Qt[(wave * 64 + k) * D + d] = qp[d];
-        st_agent(A.Qp_pub + (int64_t)k * C + (int64_t)agent * D + d, qp[d]);
       }
     }
     rz = wave_incl_sum(rz);
-    if (lane == 63) st_agent(part_rz + blockIdx.x * APB + wave, rz);
-    if (!grid_rendezvous(A.shards, A.nblk, ++epoch, A.give_up, &ok_s)) { ok = false; break; }
-    // ---- working rows: eta . d(S0 p), partials of p.H p; total of r.p -----------------------------------------------------
+    if (lane == 63) red[0][wave] = rz;
+    __syncthreads();
+    PSTAMP(3);
+    // ---- working rows: partner cells (polled until they carry this step's tag), eta . d(S0 p) ---------------------------
     {
       double sq = 0.0;
+      unsigned spins = 0;
+      bool bad = false;
       for (int e = threadIdx.x; e < ne; e += NT) {
         const int code = e_code[e];
         const int ek = code & 0xFF, al = (code >> 8) & 0xFF, side = (code >> 16) & 1;
+        const u64* pc = A.cells + e_pad[e];
+        u64 w[2 * D];
+        for (;;) {
+          bool valid = true;
+#pragma unroll
+          for (int q = 0; q < 2 * D; ++q) {
+            w[q] = ld_granule(pc + q);
+            valid = valid && (unsigned)(w[q] >> 32) == tag;
+          }
+          if (valid) break;
+          if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
+                                       __hip_atomic_load(A.give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            bad = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (bad) break;
         double s = 0.0;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-          const double pp = ld_agent(A.Qp_pub + e_pad[e] + d);
+          const double pp = __hiloint2double((int)(unsigned)w[2 * d + 1], (int)(unsigned)w[2 * d]);
           e_pp[(size_t)e * D + d] = pp;
           s += e_c[(size_t)e * D + d] * (Qt[(al * 64 + ek) * D + d] - pp);
         }
         if (!side) sq += s * s;  // every row once
       }
-      double v = 0.0;
-      for (int b = threadIdx.x; b < nparts; b += NT) v += ld_agent(part_rz + b);
+      if (bad) {
+        __hip_atomic_store(A.give_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fail_s = 1;
+      }
       sq = wave_incl_sum(sq);
-      v = wave_incl_sum(v);
-      if (lane == 63) {
-        st_agent(part_sq + blockIdx.x * APB + wave, sq);
-        red_rz[wave] = v;
+      if (lane == 63) red[1][wave] = sq;
+    }
+    __syncthreads();
+    if (fail_s) { ok = false; break; }
+    PSTAMP(4);
+    // ---- all-gather of the two partials of every workgroup -----------------------------------------------------------------
+    if (threadIdx.x < 2) {
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < APB; ++w) t += red[threadIdx.x][w];
+      st_granules(gpart + (size_t)blockIdx.x * 4 + 2 * threadIdx.x, tag, t);
+    }
+    {
+      unsigned spins = 0;
+      bool bad = false;
+      for (int q = threadIdx.x; q < 2 * nblk; q += NT) {  // one double (two granules) per thread and pass
+        u64 w0, w1;
+        for (;;) {
+          w0 = ld_granule(gpart + 2 * q);
+          w1 = ld_granule(gpart + 2 * q + 1);
+          if ((unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag) break;
+          if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
+                                       __hip_atomic_load(A.give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            bad = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (bad) break;
+        gp[q] = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
+      }
+      if (bad) {
+        __hip_atomic_store(A.give_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fail_s = 1;
       }
     }
-    if (!grid_rendezvous(A.shards, A.nblk, ++epoch, A.give_up, &ok_s)) { ok = false; break; }
+    __syncthreads();
+    if (fail_s) { ok = false; break; }
+    PSTAMP(5);
     double a;
-    {
-      double v = 0.0;
-      for (int b = threadIdx.x; b < nparts; b += NT) v += ld_agent(part_sq + b);
-      v = wave_incl_sum(v);
-      if (lane == 63) red_sq[wave] = v;
-      __syncthreads();
-      double rzt = 0.0, sqt = 0.0;
-#pragma unroll
-      for (int w = 0; w < APB; ++w) {
-        rzt += red_rz[w];
-        sqt += red_sq[w];
+    {  // every wave sums the partials in the same order: the same bits everywhere, no further barrier
+      double vr = 0.0, vs = 0.0;
+      for (int b = lane; b < nblk; b += 64) {
+        vr += gp[2 * b];
+        vs += gp[2 * b + 1];
       }
+      const double rzt = read_lane(wave_incl_sum(vr), 63);
+      const double sqt = read_lane(wave_incl_sum(vs), 63);
       const double pHp = rzt + rho_c * sqt;
       a = (pHp > 0.0 && rzt != 0.0) ? rzt / pHp : 0.0;
     }
     const double aa = alpha * a;
+    PSTAMP(6);
     // ---- everything after the step length is elementwise -------------------------------------------------------------------
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -350,6 +396,7 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
       if (last && A.emit_dy && !side) A.dyc[e_row[e]] = fmin(yn - yo, 0.0);  // u = +inf: polar of the recession cone
     }
     __syncthreads();
+    PSTAMP(7);
   }
   if (!ok) {
     if (threadIdx.x == 0) __hip_atomic_store(A.host_status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -386,6 +433,11 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
       A.yc[e_row[e]] = e_y[e];
     }
   }
+  PSTAMP(8);
+#ifdef SCP_PHASE_PROFILE
+  if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0)
+    for (int i = 0; i < 16; ++i) scp_persist_clk[i] = pacc[i];
+#endif
   if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(A.host_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -402,9 +454,9 @@ __global__ __launch_bounds__(256) void max_block_entries_kernel(int N, int K, in
   if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
 }
 
-size_t persist_lds_bytes(int K, int D, int cap) {
+size_t persist_lds_bytes(int K, int D, int cap, int nblk) {
   const int apb = CB / D;
-  size_t dbl = (size_t)2 * CB * pad_col(K) + (size_t)apb * 64 * D + (size_t)cap * (4 * D + 4);
+  size_t dbl = (size_t)2 * CB * pad_col(K) + (size_t)apb * 64 * D + (size_t)2 * nblk + (size_t)cap * (4 * D + 4);
   size_t ints = (size_t)3 * cap + (size_t)apb * K + 1;
   return dbl * sizeof(double) + ((ints + 1) / 2 * 2) * sizeof(int);
 }
@@ -437,16 +489,16 @@ int scp_qp_cg1_persist(scp_qp* qp, int nit, bool emit_dy, int* ran) {
     if (rc) return rc;
   }
   if (qp->persist_cap_nW != qp->nW) {  // working set changed: size the entry tables (one read-back per change)
-    SCP_HIP_CHECK(ctx, hipMemsetAsync(d.sync_words + 2 * NSHARD * SHARD_STRIDE, 0, 16, s));
-    hipLaunchKernelGGL(max_block_entries_kernel, dim3(4), dim3(256), 0, s, qp->N, K, apb, d.cell_ptr, (int*)(d.sync_words + 2 * NSHARD * SHARD_STRIDE));
+    SCP_HIP_CHECK(ctx, hipMemsetAsync(d.sync_words + 2, 0, 16, s));
+    hipLaunchKernelGGL(max_block_entries_kernel, dim3(4), dim3(256), 0, s, qp->N, K, apb, d.cell_ptr, (int*)(d.sync_words + 2));
     SCP_HIP_CHECK(ctx, hipGetLastError());
     int m = 0;
-    SCP_HIP_CHECK(ctx, hipMemcpyAsync(&m, d.sync_words + 2 * NSHARD * SHARD_STRIDE, sizeof(int), hipMemcpyDeviceToHost, s));
+    SCP_HIP_CHECK(ctx, hipMemcpyAsync(&m, d.sync_words + 2, sizeof(int), hipMemcpyDeviceToHost, s));
     SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));
     qp->persist_cap_nW = qp->nW;
     qp->persist_cap = (m + 63) / 64 * 64;
   }
-  const size_t lds = persist_lds_bytes(K, D, qp->persist_cap);
+  const size_t lds = persist_lds_bytes(K, D, qp->persist_cap, nblk);
   if (lds > 160 * 1024) return SCP_OK;  // too many rows around one block of agents: three-launch pipeline
   PersistArgs a;
   a.K = K; a.N = qp->N; a.nblk = nblk; a.nit = nit; a.emit_dy = emit_dy ? 1 : 0; a.ent_cap = qp->persist_cap;
@@ -456,18 +508,22 @@ int scp_qp_cg1_persist(scp_qp* qp, int nit, bool emit_dy, int* ran) {
   a.lf = d.lf; a.uf = d.uf; a.zf = d.zf; a.yf = d.yf; a.fx = d.fx; a.x = d.x;
   a.Qx = qp->qx_sel ? d.HQ : d.HQ + nx;
   a.dyf = d.dyf;
-  a.Qp_pub = d.hpf;
-  a.part = d.part;
-  a.shards = (u64*)d.sync_words;
-  a.give_up = (unsigned*)(d.sync_words + NSHARD * SHARD_STRIDE);
+  a.cells = d.cells;
+  a.gpart = d.gpart;
+  a.give_up = (unsigned*)d.sync_words;
   a.cell_ptr = d.cell_ptr; a.ent_code = d.ent_code; a.w_k = d.w_k; a.w_i = d.w_i; a.w_j = d.w_j;
   a.w_eta = d.w_eta; a.w_l = d.w_l; a.zc = d.zc; a.yc = d.yc; a.dyc = d.dyc; a.gval = d.gval;
   a.host_status = qp->h_persist_dev;
   *qp->h_persist = 0u;
-  if (qp->persist_epoch == 0)  // first launch, or the one after a give-up: every polled word starts from zero
-    SCP_HIP_CHECK(ctx, hipMemsetAsync(d.sync_words, 0, (size_t)(NSHARD * SHARD_STRIDE + 2) * sizeof(u64), s));
-  a.epoch0 = qp->persist_epoch;
-  qp->persist_epoch += 2ull * (u64)nit;  // two rendezvous per ADMM step
+  if (qp->persist_epoch == 0 || qp->persist_epoch + (u64)nit >= 0xFFFFFFF0ull) {
+    // first launch, the one after a give-up, or the step tags would wrap: every polled word starts from zero
+    SCP_HIP_CHECK(ctx, hipMemsetAsync(d.sync_words, 0, 16, s));
+    SCP_HIP_CHECK(ctx, hipMemsetAsync(d.cells, 0, (size_t)K * C * 2 * sizeof(u64), s));
+    SCP_HIP_CHECK(ctx, hipMemsetAsync(d.gpart, 0, (size_t)SCP_GPART_WORDS * sizeof(u64), s));
+    qp->persist_epoch = 0;
+  }
+  a.epoch0 = (unsigned)qp->persist_epoch;
+  qp->persist_epoch += (u64)nit;  // one tag per ADMM step
   if (D == 2) {
     if (lds > 64 * 1024)
       SCP_HIP_CHECK(ctx, scp_raise_lds_limit(ctx->device, reinterpret_cast<const void*>(cg1_persist_kernel<2>), lds));
@@ -481,3 +537,11 @@ int scp_qp_cg1_persist(scp_qp* qp, int nit, bool emit_dy, int* ran) {
   *ran = 1;
   return SCP_OK;
 }
+
+#ifdef SCP_PHASE_PROFILE
+// developer hook of the profiling build only (not declared in include/scp_hip.h)
+extern "C" int scp_debug_persist_clocks(unsigned long long* out, int n) {
+  if (n > 16) n = 16;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(scp_persist_clk), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif

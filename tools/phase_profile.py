@@ -32,6 +32,17 @@ def main():
     s._solve_with_avoidance_constraints(acc)
     torch.cuda.synchronize()
     lib = _hip.load_library()
+    pb = (C.c_ulonglong * 16)()
+    if hasattr(lib, "scp_debug_persist_clocks") and lib.scp_debug_persist_clocks(pb, 16) == 0 and sum(pb):
+        names = ["state load (once per launch)", "gather G, W', r: suffix scans", "p = Minv r (MFMA)",
+                 "S0 p, F p: forward scans, publish cells", "rows: poll partner cells, eta . dS0p", "all-gather of the partials",
+                 "step length", "updates (registers + entries)", "state write-back (once per launch)"]
+        steps = 25
+        print(f"cg1_persist_kernel, middle workgroup, last launch ({steps} steps assumed), us per step:")
+        for i, name in enumerate(names):
+            v = pb[i] * 0.01
+            print(f"  {name:44s} {v if i in (0, 8) else v / steps:8.2f} us{' (total)' if i in (0, 8) else ''}")
+        print(f"  {'sum':44s} {sum(pb) * 0.01:8.2f} us per launch")
     buf = (C.c_ulonglong * 64)()
     assert lib.scp_debug_phase_clocks(buf, 64) == 0
     t = list(buf)

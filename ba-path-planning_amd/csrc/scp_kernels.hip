@@ -390,7 +390,7 @@ struct PairArgs {
   const uint32_t* bitmap;  // working-set membership (read by the violations pass)
   uint32_t* mark;          // bits set by this pass: the bitmap itself (linearize) or a scratch map (violations)
   scp_pair_stats* stats;
-  int ablate;            // developer switch (env SCP_PAIR_ABLATE): 1 = skip the streaming stores, 2 = force no-LDS
+  int ablate;            // developer switch (profiling build, env SCP_PAIR_ABLATE): 1 = skip the streaming stores, 2 = force no-LDS
 };
 
 // [N][K][D] -> time-major P and Q = P - (p0 + (k h) v0) (either output may be NULL)
@@ -759,8 +759,12 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
   if (nq <= 0) return SCP_OK;
   const size_t lds_bytes = (size_t)(MODE == MODE_LINEARIZE ? 2 : 1) * N * D * sizeof(double);
   // the k-slice must start 16-byte aligned in global memory for the double2 staging loads: N*D even
+#ifdef SCP_PHASE_PROFILE  // developer build only (make prof): ablation switch of tools/pair_bench.py
   const char* abl = getenv("SCP_PAIR_ABLATE");
   a.ablate = abl ? atoi(abl) : 0;
+#else
+  a.ablate = 0;
+#endif
   // slices beyond 32 KB cut the occupancy below 5 workgroups per CU and the L1/L2 path wins (measured at 2048 x 50:
   // 5.43 TB/s without LDS, 4.74 with; at 1024 x 50, 32 KB: 5.0 with, 4.6 without)
   const bool use_lds = lds_bytes <= 32 * 1024 && ((N * D) % 2 == 0) && !(a.ablate & 2);

@@ -974,6 +974,10 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
         info->status_val = 1;
         break;
       }
+      // OSQP at max_iter: the same test with ten times the tolerances -> "solved inaccurate" (status 2), which the
+      // reference accepts like "solved" (scp.py:363, :446)
+      if (it >= st.max_iter && rp <= 10.0 * (st.eps_abs + st.eps_rel * np) && rd <= 10.0 * (st.eps_abs + st.eps_rel * nd))
+        info->status_val = 2;
       if (with_dy) {  // OSQP's is_primal_infeasible on the unscaled problem
         const double ndy = hs[SL_NDY], supp = hs[SL_SUPP];
         if (ndy > st.eps_prim_inf && supp < -st.eps_prim_inf * ndy) {

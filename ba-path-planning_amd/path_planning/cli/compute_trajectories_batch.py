@@ -53,7 +53,7 @@ def make_scenario(N, cfg, seed=None):
     return init_pos, final_pos, cfg["space_dims"]
 
 
-def run_single_trial(N, cfg, rng=None, seed=None, device=None, scenario=None):
+def run_single_trial(N, cfg, rng=None, seed=None, device=None, scenario=None, save_path=None):
     """One SCP solve for N vehicles -> result record (compute_trajectories_batch.py:28-67)."""
     init_pos, final_pos, space = scenario if scenario is not None else make_scenario(N, cfg, seed)
     solver = None
@@ -81,7 +81,7 @@ def run_single_trial(N, cfg, rng=None, seed=None, device=None, scenario=None):
         status = "error"
         err_msg = str(e)
     t1 = time.perf_counter()
-    return {
+    record = {
         "N": N,
         "status": status,
         "time_sec": t1 - t0,
@@ -92,6 +92,27 @@ def run_single_trial(N, cfg, rng=None, seed=None, device=None, scenario=None):
         "seed": seed,
         "scp_iterations": iters,
     }
+    if status == "success":
+        # additions to the reference record: per-iteration wall time, ADMM iterations and final
+        # residuals of every QP (QP#0 first), relative steps, convergence flag, minimum pair distance of the result
+        info = solver.last_info
+        qps = [info["qp0"]] + list(info["iterations"])
+        record.update(
+            converged=bool(info["converged"]),
+            iteration_time_sec=[float(i["time_sec"]) for i in info["iterations"]],
+            rel_steps=[float(i["rel_step"]) for i in info["iterations"]],
+            qp_iterations=[int(q["iter"]) for q in qps],
+            qp_status=[q["status"] for q in qps],
+            qp_residuals=[[float(q["r_prim"]), float(q["r_dual"])] for q in qps],
+            working_rows=[int(q["working_rows"]) for q in qps],
+        )
+        if cfg.get("validate", False):
+            record["min_pair_distance"] = float(solver.validate_solution()["min_pair_distance"])
+        if save_path is not None:
+            np.savez_compressed(save_path, initial_positions=np.asarray(init_pos), final_positions=np.asarray(final_pos),
+                                space_dims=np.asarray(space, dtype=float), **solver.trajectories)
+            record["trajectory_file"] = os.path.basename(save_path)
+    return record
 
 
 def summarise(runs, Ns):
@@ -145,6 +166,9 @@ def build_parser():
     p.add_argument("--seed", type=int, default=None)
     p.add_argument("--results-dir", default=None)
     p.add_argument("--max-iterations", type=int, default=None)
+    p.add_argument("--save-trajectories", action="store_true",
+                   help="write <results-dir>/trajectory_N<N>_t<trial>.npz (positions, velocities, accelerations) per run")
+    p.add_argument("--validate", action="store_true", help="add the minimum pair distance of every result to its record")
     p.add_argument("--streams", type=int, default=1,
                    help="solve this many scenarios concurrently on one GPU, each on its own HIP stream (a solve of "
                         "~100 agents is latency bound and leaves the GPU mostly idle)")
@@ -159,6 +183,7 @@ def main(argv=None):
                      ("max_iterations", args.max_iterations)):
         if val is not None:
             cfg[key] = val
+    cfg["validate"] = bool(args.validate)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -205,7 +230,8 @@ def main(argv=None):
     def one_job(job):
         N, trial = job
         seed = trial_seed(cfg, N, trial)
-        res = run_single_trial(N, cfg, rng=np.random, seed=seed, device=local_rank, scenario=scenarios[job])
+        save = str(Path(cfg["results_dir"]) / f"trajectory_N{N}_t{trial}.npz") if args.save_trajectories else None
+        res = run_single_trial(N, cfg, rng=np.random, seed=seed, device=local_rank, scenario=scenarios[job], save_path=save)
         res["trial_index"] = trial
         status_str = "OK" if res["status"] == "success" else f"ERR ({res['error']})"
         print(f"  [rank {rank}] N={N} trial {trial+1:02d}/{cfg['trials_per_N']}  time = {res['time_sec']:.3f}s  [{status_str}]")

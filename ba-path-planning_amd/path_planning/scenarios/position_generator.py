@@ -6,7 +6,7 @@ Two generators:
   sampling sequence as /root/reference/src/path_planning/scenarios/position_generator.py:44-75,
   :235-248, so that ``random.seed(s)`` (or the new ``seed=`` argument, which the reference leaves as
   a TODO at compute_trajectories_batch.py:40) reproduces the reference's scenarios bit for bit
-  (tests/test_scenarios.py against tests/golden/ref_generator.npz).  Capacity at R = 0.8 is about
+  (tests/test_host_cpu.py::test_generator_matches_reference_fixture against tests/golden/ref_generator.npz).  Capacity at R = 0.8 is about
   56 agents; beyond that it raises ``ValueError`` like the reference.
 * ``generate_grid_swap`` -- synthetic scenarios for N >= 64: starts on a
   jittered grid, goals = starts permuted inside blocks of ``block`` x ``block`` agents, so that every

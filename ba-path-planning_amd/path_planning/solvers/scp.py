@@ -207,10 +207,12 @@ class SCP:
         # `is_feasible` is evaluated once and never refreshed inside the loop (scp.py:144, :152)
         while iteration < max_iterations and not converged and not is_feasible:
             self._print(f"SCP Iteration {iteration+1}")
+            t_it = time.perf_counter()
             new_acc = self._solve_with_avoidance_constraints(acc)
             _, _, rel_step_norm = self._ctx.rel_step(new_acc, acc)  # scp.py:157-159 (no zero guard)
             self._print(rel_step_norm)
-            self.last_info["iterations"].append(dict(self._last_qp_info, rel_step=rel_step_norm))
+            self.last_info["iterations"].append(dict(self._last_qp_info, rel_step=rel_step_norm,
+                                                     time_sec=time.perf_counter() - t_it))
             if rel_step_norm <= self.convergence_tolerance:
                 converged = True
                 self._print(f"Converged after {iteration+1} iterations.")
@@ -355,6 +357,7 @@ class SCP:
         added = []
         info = None
         x = acc
+        max_v = 0.0
         total = {"iter": 0, "cg_iters_total": 0, "rho_updates": 0, "solve_ms": 0.0}
         for rnd in range(self.max_rounds):
             qp.update_settings(max_iter=max(max_iter - used, 1))
@@ -383,9 +386,15 @@ class SCP:
                 qp = self._grow_qp(qp.n_rows + int(new_rows.numel()), keep_state=True)
                 qp.add_rows(new_rows, n_eta, n_l)
 
-        self._last_qp_info = dict(info, **total, rounds=len(added), added=added)
+        self._last_qp_info = dict(info, **total, rounds=len(added), added=added, unresolved_rows=added[-1],
+                                  max_violation=max_v)
         if info["status_val"] not in (1, 2):  # scp.py:446-447
             self._print(f"Warning: OSQP status {info['status']}")
+        elif added[-1]:
+            # constraint generation stopped (max_rounds or the iteration budget) with violated rows still outside the
+            # working set: x solves the QP over the working set only, not the full joint QP of scp.py:399-451
+            self._print(f"Warning: OSQP status constraint generation stopped with {added[-1]} violated collision rows "
+                        f"outside the working set (max violation {max_v:.3e})")
         return x
 
     # ------------------------------------------------------------------------------------------------

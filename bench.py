@@ -33,7 +33,10 @@ sys.path.insert(0, os.path.join(ROOT, "ba-path-planning_amd"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def cpu_baseline(N, K, D, h, T, R, space, p0, pf, margin, step_info, x0):
+import numpy as np  # noqa: E402  (cpu_baseline only)
+
+
+def cpu_baseline(N, K, D, h, T, R, space, p0, pf, margin, step_info, x0, x_gpu):
     """The C oracle (oracle/scp_oracle_c.c: single-threaded CPU statement of the same algorithm, pinned against
     the numpy oracle and through it against the reference's golden vectors) runs ONE complete step -- the same
     step as the GPU, from the same input state x0 -- on one host core."""
@@ -53,7 +56,14 @@ def cpu_baseline(N, K, D, h, T, R, space, p0, pf, margin, step_info, x0):
     x1, info = co.admm(prob, eta, l_col, dist, x0, qo.Settings(max_iter=10000, margin=margin))
     t2 = time.perf_counter()
     step_s = t2 - t0
+    # parity at the benchmarked configuration: the GPU step's result against the C oracle's, same input state
+    pos_c, _ = co.kinematics(prob, x1)
+    pos_g, _ = co.kinematics(prob, x_gpu)
+    parity = {"parity_max_abs": float(np.abs(x_gpu - x1).max()), "parity_max_abs_positions": float(np.abs(pos_g - pos_c).max()),
+              "parity_note": ("max |GPU - C oracle| over the accelerations (m/s^2) / positions (m) of the timed step, both from "
+                              "the same x0 with the same settings; each side stops at an eps = 1e-3 solution of the same QP")}
     return {
+        **parity,
         "value": 1.0 / step_s,
         "unit": "SCP iterations/s",
         "cores": 1,
@@ -181,8 +191,10 @@ def main():
         },
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        x_gpu, _ = step()
         out["cpu_baseline"] = cpu_baseline(N, K, D, h, T, R, space, p0, pf, solver.working_set_margin, infos[-1],
-                                           acc0.cpu().numpy())
+                                           acc0.cpu().numpy(), x_gpu.cpu().numpy())
+        out["parity_max_abs"] = out["cpu_baseline"]["parity_max_abs"]
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     else:
         out["cpu_baseline"] = None

@@ -45,8 +45,9 @@ typedef struct scp_qp scp_qp;
 typedef struct scp_pair_stats {
   double min_dist;            /* min over processed rows of ||p_i[k] - p_j[k]|| (before the dist:=1 rule) */
   uint64_t first_violation;   /* smallest row id with dist < R - 0.01 (scp.py:610), UINT64_MAX if none */
-  uint64_t n_selected;        /* rows appended to the output list (may exceed its capacity: then only the
-                                 first `capacity` were stored and the call returned SCP_ERR_CAPACITY) */
+  uint64_t n_selected;        /* rows selected (may exceed the capacity of the output list: then only the first
+                                 `capacity` ids were stored, the call still returns SCP_OK and the caller repeats it
+                                 with a larger list) */
   double max_violation;       /* scp_collision_violations: max over rows of l_r - (A x)_r */
 } scp_pair_stats;
 
@@ -81,7 +82,8 @@ typedef struct scp_qp_settings {
 
 /* [host] result of scp_qp_solve */
 typedef struct scp_qp_info {
-  int32_t status_val;   /* OSQP codes: 1 solved, -2 maximum iterations reached, -3 primal infeasible */
+  int32_t status_val;   /* OSQP codes: 1 solved, 2 solved inaccurate (max_iter reached, 10 x eps met),
+                           -2 maximum iterations reached, -3 primal infeasible */
   int32_t iter;         /* ADMM iterations of this call */
   int32_t rho_updates;
   int32_t cg_iters_total;
@@ -187,7 +189,7 @@ int scp_qp_get_solution(scp_qp* qp, double* x_out /*[N][K][D]*/);
 /* duals: y_fixed in the reference stacking order (N*D*(4K-1)), y_col per working row (may be NULL) */
 int scp_qp_get_duals(scp_qp* qp, double* y_fixed, double* y_col);
 
-/* ---- test hooks (dense K-dimension products used by the QP; exercised by tests/test_gemm_gpu.py) ------
+/* ---- test hooks (dense K-dimension products used by the QP; exercised by tests/test_kernels_gpu.py::test_gemm_f64) ------
  * Y[R][C] = alpha * A[R][M] X[M][C] + beta * Y, row-major, device pointers. */
 int scp_gemm_f64(scp_ctx* ctx, int use_mfma, int R, int M, int C, double alpha, const double* A,
                  const double* X, double beta, double* Y);

@@ -96,3 +96,30 @@ def admm(prob, eta=None, l_col=None, dist=None, x0=None, st: qo.Settings | None 
     d = {k: getattr(info, k) for k, _ in _Info._fields_}
     d["status"] = qo.STATUS_TEXT.get(info.status_val, str(info.status_val))
     return x, d
+
+
+def scp_solve(prob, max_iterations=15, st: qo.Settings | None = None, max_iter0=4000):
+    """generate_trajectories (scp.py:131-180) on the C oracle: the same loop as qp_oracle.scp_solve, for sizes the numpy
+    oracle is too slow for (a 128-agent solve takes seconds here)."""
+    import dataclasses
+
+    st = st or qo.Settings(max_iter=10000)  # scp.py:442
+    x, info0 = admm(prob, st=dataclasses.replace(st, max_iter=max_iter0))  # OSQP default for QP#0: 4000 (scp.py:360)
+    if info0["status_val"] not in (1, 2):  # scp.py:363-365
+        raise RuntimeError(f"OSQP failed: {info0['status']}")
+    infos, rels = [info0], []
+    pos, vel = kinematics(prob, x)
+    feasible = so.check_avoidance(prob, pos)[0]
+    it, converged = 0, False
+    while it < max_iterations and not converged and not feasible:
+        eta, l_col, dist = linearize_pairs(prob, pos)
+        xn, info = admm(prob, eta, l_col, dist, x0=x, st=st)
+        infos.append(info)
+        rel = float(np.linalg.norm((xn - x).ravel()) / np.linalg.norm(x.ravel()))  # scp.py:157-159
+        rels.append(rel)
+        converged = rel <= prob.convergence_tolerance
+        x = xn
+        pos, vel = kinematics(prob, x)
+        it += 1
+    return {"positions": pos, "velocities": vel, "accelerations": x, "iterations": it, "converged": converged,
+            "initially_feasible": feasible, "rel_steps": rels, "infos": infos}

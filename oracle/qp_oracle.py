@@ -13,7 +13,7 @@ vectors at that boundary.  What pins this file inst
     solved inaccurate} (scp.py:363, :446), warm start of the primal only (scp.py:443);
   * P = 2I > 0 makes the minimiser unique, so any convergent method must agree on it: the solvers
     below are cross-checked against each other and against scipy's trust-constr at small sizes
-    (tests/test_qp_oracle.py) and against the closed-form min-norm solution when no box row is active.
+    (tests/test_host_cpu.py::test_qp_oracles_agree_and_match_trust_constr) and against the closed-form min-norm solution when no box row is active.
 
 Two solvers:
 
@@ -149,6 +149,8 @@ def osqp_explicit(P, q, A, l, u, x0=None, rho=0.1, sigma=1e-6, alpha=1.6, eps_ab
             if rp <= eps_abs + eps_rel * np_norm and rd <= eps_abs + eps_rel * nd_norm:
                 status = OSQP_SOLVED
                 break
+            if it == max_iter and rp <= 10 * (eps_abs + eps_rel * np_norm) and rd <= 10 * (eps_abs + eps_rel * nd_norm):
+                status = OSQP_SOLVED_INACCURATE  # OSQP's approximate-tolerance test at max_iter
             # primal infeasibility certificate (dy)
             dyu = E * dy
             ndy = np.abs(dyu).max()
@@ -394,6 +396,11 @@ def admm_structured(prob: so.Problem, eta=None, l_col=None, dist=None, x0=None, 
                 if rp_ <= st.eps_abs + st.eps_rel * max(nAx, nz) and rd_ <= st.eps_abs + st.eps_rel * max(nPx, nATy):
                     status = OSQP_SOLVED
                     break
+                # OSQP at max_iter: the same test with 10 x the tolerances -> "solved inaccurate" (accepted by the
+                # reference like "solved", scp.py:363, :446)
+                if total_it >= st.max_iter and rp_ <= 10 * (st.eps_abs + st.eps_rel * max(nAx, nz)) \
+                        and rd_ <= 10 * (st.eps_abs + st.eps_rel * max(nPx, nATy)):
+                    status = OSQP_SOLVED_INACCURATE
                 # primal infeasibility certificate (OSQP is_primal_infeasible): dy = y - y_prev projected onto the
                 # polar of the recession cone (collision rows have u = +inf -> dy := min(dy, 0)); all fixed rows
                 # have finite bounds
@@ -489,3 +496,45 @@ def scp_solve(prob: so.Problem, max_iterations=15, st: Settings | None = None, f
     pos, vel = so.kinematics(prob, x)
     return {"positions": pos, "velocities": vel, "accelerations": x, "iterations": it, "converged": converged,
             "initially_feasible": is_feasible, "rel_steps": rels, "infos": infos}
+
+
+def scp_solve_explicit(prob: so.Problem, max_iterations=15, log=None, **osqp_kw):
+    """generate_trajectories (scp.py:131-180) the way the reference runs it: EXPLICIT sparse matrices, P = 2 I, the
+    stack [C_jerk; C_acc; C_vel; C_pos; A_collision] with ALL N(N-1)/2 K collision rows (scp.py:407-439), a fresh
+    solver per SCP iteration with max_iter = 10000 and a primal warm start (scp.py:441-443), solved by `osqp_explicit`
+    (OSQP's published algorithm with its defaults: Ruiz scaling, eps = 1e-3) in place of the absent `osqp` package.
+    The closest available stand-in for the reference's own output; small sizes only (explicit A_collision)."""
+    n = prob.n
+    P = 2.0 * sp.eye(n, format="csc")
+    q = np.zeros(n)
+    C, lf, uf = so.stack_fixed(prob)
+    r0 = osqp_explicit(P, q, C, lf, uf, **osqp_kw)  # scp.py:360 (defaults: max_iter 4000)
+    if r0["status_val"] not in (1, 2):  # scp.py:363-365
+        raise RuntimeError(f"OSQP failed: {r0['status']}")
+    x = r0["x"]
+    infos = [r0]
+    pos, _ = so.kinematics(prob, x)
+    feasible, _ = so.check_avoidance(prob, pos)
+    it, converged, rels = 0, False, []
+    kw = dict(osqp_kw)
+    kw["max_iter"] = 10000  # scp.py:442
+    while it < max_iterations and not converged and not feasible:
+        prev_pos, _ = so.kinematics(prob, x)
+        eta, l_col, _ = so.linearize_pairs(prob, prev_pos)
+        A = sp.vstack([C, so.collision_matrix_explicit(prob, eta)], format="csc")
+        l = np.concatenate([lf, l_col])
+        u = np.concatenate([uf, np.full(l_col.shape, np.inf)])  # scp.py:479
+        r = osqp_explicit(P, q, A, l, u, x0=x, **kw)
+        infos.append(r)
+        x_new = r["x"]
+        rel = float(np.linalg.norm(x_new - x) / np.linalg.norm(x))  # scp.py:157-159
+        rels.append(rel)
+        if log:
+            log(f"SCP Iteration {it + 1}: rel_step={rel:.3e} osqp_it={r['iter']} status={r['status']}")
+        converged = rel <= prob.convergence_tolerance
+        x = x_new
+        it += 1
+    pos, vel = so.kinematics(prob, x)
+    N, K, D = prob.N, prob.K, prob.D
+    return {"positions": pos, "velocities": vel, "accelerations": x.reshape(N, K, D), "iterations": it,
+            "converged": converged, "initially_feasible": feasible, "rel_steps": rels, "infos": infos}

@@ -482,6 +482,10 @@ int oc_admm(const oc_problem* P, const double* eta, const double* l_col, const d
           status = 1;
           break;
         }
+        /* OSQP at max_iter: 10 x the tolerances -> "solved inaccurate" (scp.py:363, :446 accept it) */
+        if (total_it >= st->max_iter && rp <= 10.0 * (st->eps_abs + st->eps_rel * dmax(nAx, nz)) &&
+            rd <= 10.0 * (st->eps_abs + st->eps_rel * dmax(nPx, nATy)))
+          status = 2;
         { /* primal infeasibility certificate (OSQP is_primal_infeasible), as in qp_oracle.admm_structured */
           double ndy = 0.0, supp = 0.0;
           for (int c = 0; c < C; ++c) {

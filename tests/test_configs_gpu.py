@@ -1,0 +1,120 @@
+"""BASELINE.json's configurations as they are worded, on the GPU through the product path.
+
+  config 1: "4 agents x 20 timesteps via compute-trajectories"         -> compute_trajectories.main([...])
+  config 4: "4096 agents x 50 timesteps" (fits one GPU: 10 GB of rows)  -> tests/test_scp_gpu.py::test_full_size_properties
+  config 5: "compute-trajectories-batch: scenarios x 128 agents"        -> compute_trajectories_batch.main([...]) and a
+            128-agent grid-swap solve against the C oracle (the numpy oracle needs minutes at this size)
+"""
+import csv
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import qp_oracle as qo
+from oracle import scp_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+def test_compute_trajectories_cli_config1(tmp_path, capsys):
+    """Config 1 through the entry point: the printed lines of the reference demo (compute_trajectories.py:22-92), the
+    two plot files, and the waypoints against the CPU oracle on the same generator scenario."""
+    from path_planning.cli import compute_trajectories as cli
+    from path_planning.scenarios.position_generator import generate_positions
+
+    pre = str(tmp_path / "demo")
+    solver = cli.main(["--n-agents", "4", "--time-horizon", "10", "--time-step", "0.5", "--space", "0", "0", "20", "20",
+                       "--seed", "1", "--save-prefix", pre])
+    out = capsys.readouterr().out
+    for line in ("------ WOW Fleet Collision-Free 2D Trajectory Generation ------", "  Number of vehicles: 4",
+                 "Number of timesteps: 20", "Successfully generated positions for 4 vehicles", "Generating trajectories...",
+                 "SCP Iteration 1", "Trajectory generation complete!", "Number of time steps: 20",
+                 "Total trajectory duration: 10.0 seconds", "Visualizing 2D trajectories...", "Visualizing time snapshots"):
+        assert line in out, line
+    assert solver is not None and solver.K == 20
+    assert os.path.getsize(pre + "_2d.pdf") > 0 and os.path.getsize(pre + "_snapshots.pdf") > 0
+    p0, pf = generate_positions(4, 0.8, seed=1)
+    prob = so.make_problem(4, 10.0, 0.5, 0.8, [0, 0, 20, 20], p0, pf)
+    ref = qo.scp_solve(prob, 15, qo.Settings(max_iter=10000))
+    assert solver.last_info["n_iterations"] == ref["iterations"]
+    np.testing.assert_allclose(solver.trajectories["positions"], ref["positions"], rtol=0, atol=1e-7)
+    # the reference swallows every error and prints it (compute_trajectories.py:98-99)
+    assert cli.main(["--n-agents", "2", "--time-horizon", "1", "--time-step", "0.2", "--space", "0", "0", "200", "200",
+                     "--seed", "3", "--no-plots"]) is None
+    assert "Error during trajectory generation: OSQP failed" in capsys.readouterr().out
+
+
+def test_batch_cli_config5(tmp_path, capsys):
+    """Config 5 through the entry point with the real solver: 128-agent grid-swap scenarios; JSON / CSV schema of the
+    reference (compute_trajectories_batch.py:57-66, :91-100, :122-164), the added per-iteration fields, and one record's
+    waypoints against a direct solve of the same scenario."""
+    from path_planning.cli import compute_trajectories_batch as cli
+    from path_planning.scenarios.position_generator import generate_grid_swap
+    from path_planning.solvers.scp import SCP
+
+    res = cli.main(["--Ns", "128", "--trials", "2", "--scenario", "grid-swap", "--seed", "7", "--results-dir", str(tmp_path),
+                    "--save-trajectories", "--validate"])
+    out = capsys.readouterr().out
+    assert "------ WOW SCP Benchmark ------" in out and "Saved JSON:" in out and "Summary (success-only times):" in out
+    files = sorted(os.listdir(tmp_path))
+    jfile = [f for f in files if f.endswith(".json")][0]
+    cfile = [f for f in files if f.endswith(".csv")][0]
+    data = json.load(open(tmp_path / jfile))
+    assert set(data) == {"meta", "runs", "summary"} and data["meta"]["schema_version"] == "1.0"
+    assert set(data["meta"]) == {"timestamp", "description", "config", "schema_version"}
+    assert len(data["runs"]) == 2 and res["runs"] == data["runs"]
+    for r in data["runs"]:
+        assert {"N", "status", "time_sec", "error", "K", "T", "h", "trial_index"} <= set(r)  # the reference's record
+        assert r["N"] == 128 and r["K"] == 50 and r["status"] == "success" and r["error"] is None
+        n_it = r["scp_iterations"]
+        assert len(r["iteration_time_sec"]) == len(r["rel_steps"]) == n_it and len(r["qp_iterations"]) == n_it + 1
+        assert len(r["qp_residuals"]) == n_it + 1 and all(len(q) == 2 for q in r["qp_residuals"])
+        assert sum(r["iteration_time_sec"]) <= r["time_sec"] and all(s in ("solved", "solved inaccurate") for s in r["qp_status"])
+        if r["converged"]:
+            assert r["min_pair_distance"] >= 0.8 - 0.02
+    s = data["summary"]["128"]
+    assert set(s) == {"count", "errors", "min", "max", "mean", "median", "p25", "p75", "std"} and s["count"] == 2
+    rows = list(csv.DictReader(open(tmp_path / cfile)))
+    assert list(rows[0].keys()) == ["N", "trial_index", "status", "time_sec", "K", "T", "h", "error"] and len(rows) == 2
+    # waypoints of trial 1 == a direct solve of the same scenario (seed = rng_seed + 1000 N + trial, :108)
+    rec = data["runs"][1]
+    saved = np.load(tmp_path / rec["trajectory_file"])
+    p0, pf, space = generate_grid_swap(128, seed=rec["seed"])
+    np.testing.assert_array_equal(saved["initial_positions"], p0)
+    solver = SCP(128, 10.0, 0.2, 0.8, space, verbose=False)
+    solver.set_initial_states(p0)
+    solver.set_final_states(pf)
+    traj = solver.generate_trajectories(15)
+    np.testing.assert_array_equal(saved["positions"], traj["positions"])  # deterministic run to run
+    assert [int(q["iter"]) for q in [solver.last_info["qp0"]] + solver.last_info["iterations"]] == rec["qp_iterations"]
+
+
+@pytest.mark.parametrize("cg,tol", [(2, 1e-6), (1, 2e-2)])
+def test_scp_128_agents_vs_c_oracle(cg, tol):
+    """The unit of config 5: one 128-agent grid-swap solve against the C oracle's SCP loop.  Two PCG steps: iterate for
+    iterate (equal ADMM counts per QP, waypoints to 1e-6); the default single step: to the ADMM termination tolerance
+    (see tests/test_scp_gpu.py::test_scp_sweep_vs_oracle)."""
+    from path_planning.scenarios.position_generator import generate_grid_swap
+    from path_planning.solvers.scp import SCP
+
+    N = 128
+    p0, pf, space = generate_grid_swap(N, seed=4)
+    s = SCP(N, 10.0, 0.2, 0.8, space, verbose=False, qp_settings={"cg_iters": cg})
+    s.set_initial_states(p0)
+    s.set_final_states(pf)
+    traj = s.generate_trajectories(15)
+    prob = so.make_problem(N, 10.0, 0.2, 0.8, space, p0, pf)
+    ref = co.scp_solve(prob, 15, qo.Settings(max_iter=10000, cg_iters=cg))
+    assert s.last_info["n_iterations"] == ref["iterations"] and s.last_info["converged"] == ref["converged"]
+    gi = [s.last_info["qp0"]["iter"]] + [q["iter"] for q in s.last_info["iterations"]]
+    ci = [q["iter"] for q in ref["infos"]]
+    if cg > 1:
+        assert gi == ci
+        assert [q["working_rows"] for q in s.last_info["iterations"]] == [q["working_rows"] for q in ref["infos"][1:]]
+    else:
+        assert all(abs(a - b) <= 50 for a, b in zip(gi, ci)), (gi, ci)
+    np.testing.assert_allclose(traj["positions"], ref["positions"], rtol=0, atol=tol)
+    np.testing.assert_allclose([q["rel_step"] for q in s.last_info["iterations"]], ref["rel_steps"], rtol=0.05, atol=2e-3)

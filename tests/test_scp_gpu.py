@@ -323,14 +323,16 @@ def test_scp_sweep_vs_oracle(kind, n, seed, cg):
     check_solution_properties(s, traj)
 
 
-def test_full_size_properties_1024x50():
-    """BASELINE config 3 at full size (1024 agents x 50 steps, 26.2 M collision rows): the oracle cannot finish a
-    solve here in test time, so the check is through size-independent properties."""
+@pytest.mark.parametrize("N", [1024, 4096])
+def test_full_size_properties(N):
+    """BASELINE configs 3 and 4 at full size (1024 / 4096 agents x 50 steps: 26.2 M / 419 M collision rows, 0.6 / 10 GB
+    of compact rows on one GPU): the oracle cannot finish a solve here in test time, so the check is through
+    size-independent properties."""
     import torch
 
     from path_planning.scenarios.position_generator import generate_grid_swap
 
-    N, K = 1024, 50
+    K = 50
     p0, pf, space = generate_grid_swap(N, seed=1000 * N)
     s, traj = solve_gpu(N, K * 0.2 + 1e-9, 0.2, 0.8, space, p0, pf, max_iterations=15)
     assert s.K == K and s.last_info["converged"] and 1 <= s.last_info["n_iterations"] <= 15
@@ -348,7 +350,7 @@ def test_full_size_properties_1024x50():
     rows, min_dist, first = pp.linearize(pos, p0d, v0d, s.working_set_margin)
     assert first == (1 << 64) - 1 and abs(min_dist - rep["min_pair_distance"]) < 1e-12
     rng = np.random.default_rng(0)
-    sample = np.sort(rng.choice(prob.m_col, 20000, replace=False))
+    sample = np.unique(rng.integers(0, prob.m_col, 20000))  # (no permutation of 4.2e8 row ids at N = 4096)
     st = torch.as_tensor(sample, dtype=torch.int64, device=ctx.tdev)
     w_eta, w_l = pp.gather(st)
     iu, ju = so.pair_index(N)
@@ -370,3 +372,70 @@ def test_full_size_properties_1024x50():
     # at the returned solution no linearised row (around that same solution) is violated beyond the tolerance
     new_rows, max_v = pp.violations(pos, p0d, v0d, 1e-6)
     assert max_v <= 0.8 - rep["min_pair_distance"] + 1e-9  # l - A x = R - dist at the linearisation point itself
+
+
+def test_unresolved_rows_are_reported(capsys):
+    """Constraint generation cut short (max_rounds = 1, a working set that starts empty): the QP over the working set
+    reports "solved" although violated collision rows remain outside it -- the solver must say so (reference-style
+    warning line) and record the count, instead of passing the point off as the joint QP's solution."""
+    p0, pf = ref_scenario(10, 7)
+    from path_planning.solvers.scp import SCP
+
+    s = SCP(10, 10.0, 0.2, 0.8, [0, 0, 20, 20], verbose=True, max_rounds=1, working_set_margin=-1.0)
+    s.set_initial_states(p0)
+    s.set_final_states(pf)
+    capsys.readouterr()
+    s.generate_trajectories(max_iterations=1)
+    out = capsys.readouterr().out
+    info = s.last_info["iterations"][0]
+    assert info["unresolved_rows"] > 0 and info["max_violation"] > 1e-3 and info["rounds"] == 1
+    assert "Warning: OSQP status constraint generation stopped" in out
+    # the default settings resolve every row
+    s2, _ = solve_gpu(10, 10.0, 0.2, 0.8, [0, 0, 20, 20], p0, pf, max_iterations=1)
+    assert s2.last_info["iterations"][0]["unresolved_rows"] == 0
+
+
+@pytest.mark.parametrize("kind,n,seed", [("ref", 6, 11), ("ref", 12, 13), ("grid", 25, 15), ("grid", 36, 16)])
+def test_default_path_reaches_the_oracle_minimiser(kind, n, seed):
+    """The default single-PCG-step path against the oracle at eps = 1e-8: each QP has ONE minimiser (P = 2I > 0), so
+    with tight tolerances both implementations must land on it whatever their summation orders -- waypoints to 1e-6
+    over whole SCP solves (the 2e-2 of test_scp_sweep_vs_oracle at eps = 1e-3 is the solver tolerance, not a property
+    of the path)."""
+    from path_planning.scenarios.position_generator import generate_grid_swap
+
+    if kind == "ref":
+        p0, pf = ref_scenario(n, seed)
+        space = [0, 0, 20, 20]
+    else:
+        p0, pf, space = generate_grid_swap(n, seed=seed)
+    tight = {"eps_abs": 1e-8, "eps_rel": 1e-8, "max_iter": 40000, "max_iter0": 40000}
+    s, traj = solve_gpu(n, 10.0, 0.2, 0.8, space, p0, pf, max_iterations=3, qp_settings=tight)
+    assert s._qp.settings.cg_iters == 1 and s._qp.settings.persistent == 1  # the defaults
+    prob = so.make_problem(n, 10.0, 0.2, 0.8, space, p0, pf)
+    from oracle import c_oracle as co
+
+    ref = co.scp_solve(prob, 3, qo.Settings(max_iter=40000, eps_abs=1e-8, eps_rel=1e-8), max_iter0=40000)
+    assert s.last_info["n_iterations"] == ref["iterations"]
+    for a, b in zip(s.last_info["iterations"], ref["infos"][1:]):
+        assert a["status_val"] == b["status_val"] == 1 and a["working_rows"] == b["working_rows"], (a, b)
+    np.testing.assert_allclose(traj["positions"], ref["positions"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(traj["accelerations"], ref["accelerations"], rtol=0, atol=1e-5)
+
+
+PROXY_TOL = 6e-2  # metres; OSQP's own accuracy at eps = 1e-3 (INTEGRATION.md, "distance to the reference")
+
+
+@pytest.mark.parametrize("n,seed", [(4, 1), (6, 11), (10, 7)])
+def test_against_reference_proxy(n, seed):
+    """Distance to the reference as far as it can be stated without the `osqp` package: the reference's own loop on
+    EXPLICIT matrices with all collision rows and OSQP's published algorithm at its defaults (Ruiz scaling, eps = 1e-3:
+    qp_oracle.scp_solve_explicit) against the GPU result at its defaults.  Both stop at eps = 1e-3 solutions of the same
+    QPs, so the waypoints agree to OSQP's accuracy, PROXY_TOL; the SCP iteration count may differ by one."""
+    p0, pf = ref_scenario(n, seed)
+    s, traj = solve_gpu(n, 10.0, 0.5, 0.8, [0, 0, 20, 20], p0, pf)
+    prob = so.make_problem(n, 10.0, 0.5, 0.8, [0, 0, 20, 20], p0, pf)
+    ref = qo.scp_solve_explicit(prob, 15)
+    assert ref["converged"] and s.last_info["converged"]
+    assert abs(s.last_info["n_iterations"] - ref["iterations"]) <= 1
+    np.testing.assert_allclose(traj["positions"], ref["positions"], rtol=0, atol=PROXY_TOL)
+    assert so.min_pair_distance(prob, traj["positions"]) >= 0.8 - 0.01  # scp.py:610

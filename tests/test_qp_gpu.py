@@ -218,8 +218,10 @@ def test_qp_errors(ctx):
 @pytest.mark.parametrize("n,seed,dim", [(10, 7, 2), (24, 5, 2), (7, 3, 3)])
 def test_persistent_kernel_equals_three_launch_pipeline(ctx, n, seed, dim):
     """settings.persistent: the persistent single-step kernel (state on chip, tagged-granule exchanges) and the
-    three-launch pipeline run the same arithmetic -- after 60 ADMM steps (two launches of the persistent kernel with a
-    termination check in between) every piece of solver state agrees to rounding, and both agree with the oracle."""
+    three-launch pipeline run the same arithmetic -- after 12 ADMM steps (two launches of the persistent kernel with a
+    termination check in between) every piece of solver state agrees to rounding, and both agree with the oracle.
+    (Only the summation order of the line-search partials differs; over hundreds of steps the single-step ADMM map can
+    amplify that 1e-16 -- see test_scp_sweep_vs_oracle -- so the comparison is made early.)"""
     import torch
     from path_planning.scenarios.position_generator import generate_grid_swap
 
@@ -238,21 +240,21 @@ def test_persistent_kernel_equals_three_launch_pipeline(ctx, n, seed, dim):
     for persistent in (1, 0):
         from path_planning import _hip
 
-        st = _hip.default_settings(cg_iters=1, persistent=persistent, max_iter=60, check_termination=30, adaptive_rho=0,
+        st = _hip.default_settings(cg_iters=1, persistent=persistent, max_iter=12, check_termination=6, adaptive_rho=0,
                                    eps_abs=1e-12, eps_rel=1e-12)
         qp = _hip.QP(ctx, prob.N, prob.K, prob.D, prob.h, st)
         qp.set_problem(LIMITS, space, ctx.tensor(prob.p0), ctx.tensor(prob.v0), ctx.tensor(prob.pf), ctx.tensor(prob.vf))
         qp.reset(ctx.tensor(x0))
         qp.add_rows(torch.as_tensor(W, dtype=torch.int64, device=ctx.tdev), ctx.tensor(eta[W]), ctx.tensor(l_col[W]))
         info = qp.solve()
-        assert info["iter"] == 60 and info["status_val"] == -2
+        assert info["iter"] == 12 and info["status_val"] == -2
         states[persistent] = {k: qp.peek(k).cpu().numpy() for k in ("x", "zf", "yf", "fx", "qx", "zc", "yc", "gval")}
         states[persistent]["sol"] = qp.solution().cpu().numpy()
         qp.close()
     for k in states[1]:
         scale = max(1.0, np.abs(states[0][k]).max())
-        np.testing.assert_allclose(states[1][k], states[0][k], rtol=0, atol=1e-10 * scale, err_msg=k)
-    so_ = oracle_settings(cg_iters=1, max_iter=60, check_termination=30, adaptive_rho=False, eps_abs=1e-12, eps_rel=1e-12,
+        np.testing.assert_allclose(states[1][k], states[0][k], rtol=0, atol=1e-11 * scale, err_msg=k)
+    so_ = oracle_settings(cg_iters=1, max_iter=12, check_termination=6, adaptive_rho=False, eps_abs=1e-12, eps_rel=1e-12,
                           max_rounds=1)
     xo, _, _ = qo.admm_structured(prob, eta, l_col, dist, x0=x0, st=so_, rows0=W)
     np.testing.assert_allclose(states[1]["sol"], xo, rtol=0, atol=1e-8)

@@ -513,6 +513,7 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.sync_words = c.take<unsigned long long>(SCP_SYNC_WORDS);
   d.cells = c.take<unsigned long long>((size_t)2 * nx);
   d.gpart = c.take<unsigned long long>(SCP_GPART_WORDS);
+  d.gcheck = c.take<unsigned long long>(SCP_GCHECK_WORDS);
   return c.off;
 }
 
@@ -912,56 +913,55 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
   int cg_total = 0, it = 0;
   double rp = INFINITY, rd = INFINITY;
   while (it < st.max_iter) {
-    // fixed rows only (everything is column-local), or the persistent single-step kernel: every iteration up to the
-    // next termination check goes into ONE launch
+    // fixed rows only (everything is column-local): every iteration up to the next termination check goes into ONE
+    // launch; the persistent single-step kernel goes further and runs the checks itself, returning only when the host has
+    // something to decide (solved, infeasible, iteration limit, a rho update)
     const bool qp0_it = fused && qp->nW == 0;
     const bool cg1_it = fused && st.cg_iters == 1 && qp->nW > 0;  // its update kernel emits delta-y itself
-    const bool persist_it = cg1_it && scp_qp_persist_eligible(qp);
+    bool persist_done = false;
+    if (cg1_it && scp_qp_persist_eligible(qp)) {
+      int ran = 0, code = 0, it_done = it;
+      QP_CHECK(scp_qp_cg1_persist(qp, it, &ran, &code, &it_done));
+      if (ran && code == SCP_PERSIST_GAVE_UP) {
+        // its workgroups were not all resident at once (e.g. the device is shared with another stream's kernels): nothing
+        // was written back, so the solve goes on from the same state on the three-launch pipeline and stays there
+        qp->persist_off = true;
+        qp->persist_epoch = 0;
+      } else if (ran) {
+        cg_total += it_done - it;
+        it = it_done;
+        qp->qx_fresh = true;  // the kernel's last check left F x and S0 x exact
+        persist_done = true;
+      }
+    }
     int n_it = 1;
-    if (qp0_it || persist_it) {
+    if (!persist_done && qp0_it) {
       n_it = st.check_termination - it % st.check_termination;
       if (it + n_it > st.max_iter) n_it = st.max_iter - it;
     }
-    it += n_it;
-    const bool will_check = it % st.check_termination == 0 || it >= st.max_iter;
+    if (!persist_done) it += n_it;
+    const bool will_check = persist_done || it % st.check_termination == 0 || it >= st.max_iter;
     const bool with_dy = will_check && st.eps_prim_inf > 0.0;
-    if (with_dy && !cg1_it && !qp0_it) {  // snapshot of the duals: delta-y of this iteration feeds the certificate
-      SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->d.dyf, qp->d.yf, (size_t)qp->Rf * qp->C * sizeof(double),
-                                        hipMemcpyDeviceToDevice, ctx->stream));
-      if (qp->nW > 0)
-        SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->d.dyc, qp->d.yc, (size_t)qp->nW * sizeof(double),
+    if (!persist_done) {
+      if (with_dy && !cg1_it && !qp0_it) {  // snapshot of the duals: delta-y of this iteration feeds the certificate
+        SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->d.dyf, qp->d.yf, (size_t)qp->Rf * qp->C * sizeof(double),
                                           hipMemcpyDeviceToDevice, ctx->stream));
-    }
-    bool persist_ran = false;
-    if (persist_it) {
-      int ran = 0;
-      QP_CHECK(scp_qp_cg1_persist(qp, n_it, with_dy, &ran));
-      persist_ran = ran != 0;
-      if (persist_ran) cg_total += n_it;
-    }
-    if (persist_ran) {
-      // (its completion status is read after the check below has drained the stream)
-    } else if (cg1_it) {
-      for (int j = 0; j < n_it; ++j) QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total, with_dy && j == n_it - 1));
-    } else if (qp0_it) {
-      QP_CHECK(scp_qp_qp0_iterations(qp, n_it, with_dy ? qp->d.dyf : nullptr));
-    } else if (fused) {
-      QP_CHECK(scp_qp_fused_iteration(qp, &cg_total));
-    } else {
-      QP_CHECK(admm_iteration(qp, &cg_total));
+        if (qp->nW > 0)
+          SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->d.dyc, qp->d.yc, (size_t)qp->nW * sizeof(double),
+                                            hipMemcpyDeviceToDevice, ctx->stream));
+      }
+      if (cg1_it) QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total, with_dy));
+      else if (qp0_it) QP_CHECK(scp_qp_qp0_iterations(qp, n_it, with_dy ? qp->d.dyf : nullptr));
+      else if (fused) QP_CHECK(scp_qp_fused_iteration(qp, &cg_total));
+      else QP_CHECK(admm_iteration(qp, &cg_total));
     }
     if (will_check) {
-      if (cg1_it || qp0_it) QP_CHECK(scp_qp_fused_residuals(qp, with_dy));
-      else QP_CHECK(residuals(qp, with_dy));
-      if (persist_ran && *(volatile unsigned*)qp->h_persist != 1u) {
-        // The persistent launch gave up (its workgroups were not all resident at once, e.g. the device is shared with
-        // another stream's kernels): nothing was written back, so the iterations are repeated on the three-launch
-        // pipeline from the same state and this solver stays there.
-        qp->persist_off = true;
-        qp->persist_epoch = 0;
-        cg_total -= n_it;
-        for (int j = 0; j < n_it; ++j) QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total, with_dy && j == n_it - 1));
+      if (persist_done) {
+        // (the kernel left the nine check results in h_scal)
+      } else if (cg1_it || qp0_it) {
         QP_CHECK(scp_qp_fused_residuals(qp, with_dy));
+      } else {
+        QP_CHECK(residuals(qp, with_dy));
       }
       if (!cg1_it) qp->cg1_ready = false;  // residuals() used G and the Q slabs as scratch (the fused check keeps
                                            // the pipeline's carried state and refreshes S0 x, F x exactly)

@@ -47,6 +47,7 @@ struct QpDev {
   unsigned long long* sync_words;  // SCP_SYNC_WORDS: give-up word of the persistent kernel, scratch
   unsigned long long* cells;       // [K][N][D][2] tagged granules: S0 p cells published by the persistent kernel
   unsigned long long* gpart;       // SCP_GPART_WORDS tagged granules: line-search partials, two alternating buffers
+  unsigned long long* gcheck;      // SCP_GCHECK_WORDS tagged granules: termination-check partials
 };
 
 struct scp_qp {
@@ -71,7 +72,7 @@ struct scp_qp {
   int64_t persist_cap_nW;            // working-set size the entry capacity below was measured for (-1: none)
   int persist_cap;                   // LDS entry capacity per workgroup = most entries around any block of agents
   unsigned long long persist_epoch;  // ADMM steps run by persistent launches so far: the step tags of the granules never repeat
-  unsigned* h_persist;               // mapped host word written by the kernel: 1 done, 2 gave up
+  unsigned* h_persist;               // mapped host words written by the kernel: [0] exit code, [1] iterations done
   unsigned* h_persist_dev;
 };
 
@@ -95,8 +96,10 @@ int scp_qp_csr_build(scp_qp* qp);
 int scp_qp_cg1_prepare(scp_qp* qp);
 constexpr int SCP_SYNC_WORDS = 16;  // u64: give-up word | scratch
 constexpr int SCP_GPART_WORDS = 2 * 256 * 4;  // two buffers x (at most one workgroup per CU) x two doubles as granule pairs
+constexpr int SCP_GCHECK_WORDS = 256 * 9 * 2;  // nine check results per workgroup as granule pairs
 bool scp_qp_persist_eligible(const scp_qp* qp);
-int scp_qp_cg1_persist(scp_qp* qp, int nit, bool emit_dy, int* ran);
+constexpr int SCP_PERSIST_GAVE_UP = 2;  // exit code of the persistent kernel: a spin timed out, nothing was written back
+int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done);
 // (re)pack F, Ft, S0, S0t, HS, Minv into the MFMA operand order; called at the end of build_kkt
 int scp_qp_pack_operands(scp_qp* qp);
 static inline size_t scp_packed_count(int R, int M) { return (size_t)((R + 15) / 16) * ((M + 3) / 4) * 64; }

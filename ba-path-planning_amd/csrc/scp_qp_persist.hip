@@ -25,6 +25,8 @@
 // state back, and the host repeats the iterations on the three-launch pipeline.
 #include "scp_qp_device.h"
 
+#include <chrono>
+
 namespace {
 using namespace scpdev;
 
@@ -46,21 +48,32 @@ __device__ unsigned long long scp_persist_clk[16];
 #endif
 
 struct PersistArgs {
-  int K, N, nblk, nit, emit_dy, ent_cap;
+  int K, N, nblk, ent_cap;
+  int it0, max_iter, check_every, rho_interval;  // iterations done so far in this solve; limits; termination / rho periods
   int64_t C;
   double rho, rho_c, rho_eq, alpha, h;
+  double eps_abs, eps_rel, eps_prim_inf, rho_tol;  // termination tests (eps_prim_inf <= 0: no certificate; rho_tol <= 0: fixed rho)
   const double* pMinv;
   const double *lf, *uf;
   double *zf, *yf, *fx, *x, *Qx, *dyf;
   u64* cells;       // [K][N][D][2] granules: S0 p of (time step, agent), low / high word, each tagged with the step
   u64* gpart;       // [2 parities][nblk][4] granules: r.p and sum (eta . d S0 p)^2 of one workgroup
+  u64* gcheck;      // [nblk][18] granules: the nine partial results of a termination check of one workgroup
   unsigned* give_up;
   const int *cell_ptr, *ent_code, *w_k, *w_i, *w_j;
   const double *w_eta, *w_l;
   double *zc, *yc, *dyc, *gval;
-  unsigned* host_status;  // mapped host word: 1 = all steps done, 2 = gave up
+  unsigned* host_status;  // mapped host words: [0] exit code (EXIT_*), [1] ADMM iterations done when the kernel left
+  double* host_scal;      // mapped host array: the nine check results in the SL_* slots of scp_qp::h_scal
+  u64* host_flag;         // mapped completion word, set to `seq` last
+  u64 seq;
   unsigned epoch0;        // steps completed by earlier launches (tags never repeat; the buffers start zeroed)
 };
+
+// why the kernel returned (host_status[0]); the host re-derives every decision from the nine check results
+enum { EXIT_SOLVED = 1, EXIT_GAVE_UP = 2, EXIT_MAX_ITER = 3, EXIT_INFEASIBLE = 4, EXIT_RHO = 5 };
+constexpr int NCHK = 9;  // rp, |Ax|, |z|, rd, |Px|, |A^T y|, |dy|, supp (a sum), |A^T dy|  (maxima of non-negative values)
+constexpr int CK_RP = 0, CK_NAX = 1, CK_NZ = 2, CK_RD = 3, CK_NPX = 4, CK_NATY = 5, CK_NDY = 6, CK_SUPP = 7, CK_NATDY = 8;
 
 __device__ inline void st_granules(u64* g, unsigned tag, double v) {
   const u64 t = (u64)tag << 32;
@@ -74,7 +87,7 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
   constexpr int APB = CB / D;    // agents = waves per workgroup
   constexpr int NT = 64 * APB;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  __shared__ double red[2][APB];
+  __shared__ double red[NCHK][APB];
   __shared__ int fail_s;
   const int K = A.K, N = A.N;
   const int64_t C = A.C;
@@ -83,8 +96,8 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
   double* Rt = lds;                        // [16][RSK]   r, MFMA B operand
   double* Pt = Rt + CB * RSK;              // [16][RSK]   p
   double* Qt = Pt + CB * RSK;              // [APB][64][D] own S0 p cells
-  double* gp = Qt + APB * 64 * D;          // [nblk][2]   all-gathered partials (r.p, row term)
-  double* e_c = gp + 2 * A.nblk;           // [cap][D] signed eta (+ on agent i's side, - on agent j's)
+  double* gp = Qt + APB * 64 * D;          // [nblk][9]   all-gathered partials (line search: 2 per workgroup; check: 9)
+  double* e_c = gp + NCHK * A.nblk;        // [cap][D] signed eta (+ on agent i's side, - on agent j's)
   double* e_l = e_c + (size_t)cap * D;     // [cap] lower bound
   double* e_z = e_l + cap;                 // [cap]
   double* e_y = e_z + cap;                 // [cap]
@@ -114,7 +127,8 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
   if (ne > cap) {  // cannot happen when the host sized the launch from the entry counts; never spin on it
     if (threadIdx.x == 0) {
       __hip_atomic_store(A.give_up, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(A.host_status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(A.host_status, (unsigned)EXIT_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(A.host_flag, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     return;
   }
@@ -183,8 +197,16 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
   PSTAMP(0);
   bool ok = true;
   double dy[D][4];
-  for (int it = 0; it < A.nit; ++it) {
-    const unsigned tag = A.epoch0 + (unsigned)it + 1u;
+  int it_done = A.it0;      // ADMM iterations of this solve completed so far
+  unsigned steps = 0;       // steps run by this launch
+  unsigned exit_code = 0;
+  double chk[NCHK];
+  const bool with_dy = A.eps_prim_inf > 0.0;
+  for (;;) {  // one batch of steps up to the next termination check, then the check and the decision to go on
+  int nit = A.check_every - it_done % A.check_every;
+  if (it_done + nit > A.max_iter) nit = A.max_iter - it_done;
+  for (int it = 0; it < nit; ++it, ++steps) {
+    const unsigned tag = A.epoch0 + steps + 1u;
     u64* gpart = A.gpart + (size_t)(tag & 1u) * nblk * 4;
     // ---- r = -2 x + F^T W' + S0^T G: reverse cumulative sums as suffix scans over the lanes ------------------------
     double r[D];
@@ -370,10 +392,10 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
       x[d] = fma(aa, p[d], x[d]);
       qx[d] = fma(aa, qp[d], qx[d]);
     }
-    const bool last = it == A.nit - 1;
+    const bool last = it == nit - 1;
     for (int e = threadIdx.x; e < ne; e += NT) {
       const int code = e_code[e];
-      const int ek = code & 0xFF, al = (code >> 8) & 0xFF, side = (code >> 16) & 1;
+      const int ek = code & 0xFF, al = (code >> 8) & 0xFF;
       double tc = 0.0, ax = 0.0;
 #pragma unroll
       for (int d = 0; d < D; ++d) {
@@ -393,13 +415,208 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
       e_z[e] = zn;
       e_y[e] = yn;
       e_g[e] = (rho_c * zn - yn) - rho_c * ax;
-      if (last && A.emit_dy && !side) A.dyc[e_row[e]] = fmin(yn - yo, 0.0);  // u = +inf: polar of the recession cone
+      if (last && with_dy) e_pp[(size_t)e * D] = fmin(yn - yo, 0.0);  // delta-y of the batch's last step (u = +inf: polar of
+                                                                      // the recession cone), parked until the check
     }
     __syncthreads();
     PSTAMP(7);
   }
+
+  if (!ok) break;
+  it_done += nit;
+  // ==== termination check (replaces 4 launches + a host round trip per check) ==========================================
+  // Same quantities as scp_qp_fused_residuals: F x and S0 x are rebuilt exactly from x (the carried slabs are refreshed,
+  // as the three-launch pipeline does at every check), A^T y = F^T y_f + S0^T G(y_c) by suffix scans, the primal
+  // infeasibility certificate from delta-y of the last step.  One more neighbour hand-off (exact S0 x cells, tagged with
+  // bit 31 set) and one all-gather of nine values per workgroup.
+  {
+    const unsigned ctag = 0x80000000u | (A.epoch0 + steps);
+    double m[NCHK];
+#pragma unroll
+    for (int j = 0; j < NCHK; ++j) m[j] = 0.0;
+    {
+      double gy[D], gd[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) gy[d] = gd[d] = 0.0;
+      for (int e = c0; e < c1; ++e) {
+        const double ye = e_y[e], de = with_dy ? e_pp[(size_t)e * D] : 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          gy[d] += e_c[(size_t)e * D + d] * ye;
+          gd[d] += e_c[(size_t)e * D + d] * de;
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        // exact F x, S0 x from x (forward scans)
+        const double cs1 = wave_incl_sum(x[d]);
+        const double cs2 = lane_below(wave_incl_sum(cs1));
+        const double cs1p = lane_below(cs1);
+        const double xn = lane_above(x[d]);
+        fx[d][0] = (live && k < K - 1) ? (xn - x[d]) / h : 0.0;
+        fx[d][1] = x[d];
+        fx[d][2] = live ? h * cs1 : 0.0;
+        fx[d][3] = live ? hh * (cs2 + 0.5 * cs1) : 0.0;
+        qx[d] = hh * (cs2 - 0.5 * cs1p);
+        if (c1 > c0) {
+          st_granules(my_cell + 2 * d, ctag, qx[d]);
+          Qt[(wave * 64 + k) * D + d] = qx[d];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (live && (t > 0 || k < K - 1)) {
+            m[CK_RP] = fmax(m[CK_RP], fabs(fx[d][t] - z[d][t]));
+            m[CK_NAX] = fmax(m[CK_NAX], fabs(fx[d][t]));
+            m[CK_NZ] = fmax(m[CK_NZ], fabs(z[d][t]));
+            if (with_dy) {
+              m[CK_NDY] = fmax(m[CK_NDY], fabs(dy[d][t]));
+              m[CK_SUPP] += hi[d][t] * fmax(dy[d][t], 0.0) + lo[d][t] * fmin(dy[d][t], 0.0);
+            }
+          }
+        }
+        // A^T y (and A^T delta-y): the r chain with W' -> y
+        for (int pass = 0; pass < (with_dy ? 2 : 1); ++pass) {
+          const double vj = pass ? dy[d][0] : y[d][0], va = pass ? dy[d][1] : y[d][1];
+          const double vv = pass ? dy[d][2] : y[d][2], vp = pass ? dy[d][3] : y[d][3];
+          const double g = pass ? gd[d] : gy[d];
+          const double u1 = h * vv + 0.5 * hh * (vp - g);
+          const double u2 = vp + g;
+          const double d1 = wave_incl_rsum(u1);
+          const double s1 = wave_incl_rsum(u2);
+          const double d2 = lane_above(wave_incl_rsum(s1));
+          const double vjm = lane_below(vj);
+          const double at = ((vjm - vj) / h + va) + (d1 + 0.5 * hh * g) + hh * d2;
+          if (live) {
+            if (pass) {
+              m[CK_NATDY] = fmax(m[CK_NATDY], fabs(at));
+            } else {
+              const double px = 2.0 * x[d];
+              m[CK_RD] = fmax(m[CK_RD], fabs(px + at));
+              m[CK_NPX] = fmax(m[CK_NPX], fabs(px));
+              m[CK_NATY] = fmax(m[CK_NATY], fabs(at));
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    {  // collision rows: exact S0 x cells of both agents (the carried copies are refreshed), residuals, delta-y
+      unsigned spins = 0;
+      bool bad = false;
+      for (int e = threadIdx.x; e < ne; e += NT) {
+        const int code = e_code[e];
+        const int ek = code & 0xFF, al = (code >> 8) & 0xFF, side = (code >> 16) & 1;
+        const u64* pc = A.cells + e_pad[e];
+        u64 w[2 * D];
+        for (;;) {
+          bool valid = true;
+#pragma unroll
+          for (int q = 0; q < 2 * D; ++q) {
+            w[q] = ld_granule(pc + q);
+            valid = valid && (unsigned)(w[q] >> 32) == ctag;
+          }
+          if (valid) break;
+          if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
+                                       __hip_atomic_load(A.give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            bad = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (bad) break;
+        double ax = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const double qq = __hiloint2double((int)(unsigned)w[2 * d + 1], (int)(unsigned)w[2 * d]);
+          const double qo = Qt[(al * 64 + ek) * D + d];
+          e_qo[(size_t)e * D + d] = qo;
+          e_qp[(size_t)e * D + d] = qq;
+          ax += e_c[(size_t)e * D + d] * (qo - qq);
+        }
+        if (!side) {
+          const double zc_ = e_z[e];
+          m[CK_RP] = fmax(m[CK_RP], fabs(ax - zc_));
+          m[CK_NAX] = fmax(m[CK_NAX], fabs(ax));
+          m[CK_NZ] = fmax(m[CK_NZ], fabs(zc_));
+          if (with_dy) {
+            const double dd = e_pp[(size_t)e * D];
+            m[CK_NDY] = fmax(m[CK_NDY], fabs(dd));
+            m[CK_SUPP] += e_l[e] * dd;
+          }
+        }
+      }
+      if (bad) {
+        __hip_atomic_store(A.give_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fail_s = 1;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NCHK; ++j) {
+      const double v = j == CK_SUPP ? wave_incl_sum(m[j]) : wave_max_nn(m[j]);
+      if (lane == 63) red[j][wave] = v;
+    }
+    __syncthreads();
+    if (fail_s) { ok = false; break; }
+    if (threadIdx.x < NCHK) {
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < APB; ++w) t = threadIdx.x == CK_SUPP ? t + red[threadIdx.x][w] : fmax(t, red[threadIdx.x][w]);
+      st_granules(A.gcheck + ((size_t)blockIdx.x * NCHK + threadIdx.x) * 2, ctag, t);
+    }
+    {
+      unsigned spins = 0;
+      bool bad = false;
+      for (int q = threadIdx.x; q < NCHK * nblk; q += NT) {
+        u64 w0, w1;
+        for (;;) {
+          w0 = ld_granule(A.gcheck + 2 * q);
+          w1 = ld_granule(A.gcheck + 2 * q + 1);
+          if ((unsigned)(w0 >> 32) == ctag && (unsigned)(w1 >> 32) == ctag) break;
+          if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
+                                       __hip_atomic_load(A.give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            bad = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (bad) break;
+        gp[q] = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
+      }
+      if (bad) {
+        __hip_atomic_store(A.give_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fail_s = 1;
+      }
+    }
+    __syncthreads();
+    if (fail_s) { ok = false; break; }
+#pragma unroll
+    for (int j = 0; j < NCHK; ++j) {  // the same reduction order in every wave of every workgroup: identical decisions
+      double v = 0.0;
+      for (int b = lane; b < nblk; b += 64) v = j == CK_SUPP ? v + gp[b * NCHK + j] : fmax(v, gp[b * NCHK + j]);
+      chk[j] = read_lane(j == CK_SUPP ? wave_incl_sum(v) : wave_max_nn(v), 63);
+    }
+    __syncthreads();  // gp is reused by the next step's all-gather
+    // ---- decide (the host repeats these tests on the same nine numbers, scp_qp_solve) ------------------------------------
+    const double np_ = fmax(chk[CK_NAX], chk[CK_NZ]), nd_ = fmax(chk[CK_NPX], chk[CK_NATY]);
+    if (chk[CK_RP] <= A.eps_abs + A.eps_rel * np_ && chk[CK_RD] <= A.eps_abs + A.eps_rel * nd_) { exit_code = EXIT_SOLVED; break; }
+    if (it_done >= A.max_iter) { exit_code = EXIT_MAX_ITER; break; }
+    if (with_dy && chk[CK_NDY] > A.eps_prim_inf && chk[CK_SUPP] < -A.eps_prim_inf * chk[CK_NDY] &&
+        chk[CK_NATDY] < A.eps_prim_inf * chk[CK_NDY]) { exit_code = EXIT_INFEASIBLE; break; }
+    if (A.rho_tol > 0.0 && it_done % A.rho_interval == 0) {
+      // rho estimate as the host computes it, BEFORE its snap to the 2^(1/4) grid (which moves it by at most 2^(1/8)):
+      // leave whenever the snapped value could cross the update threshold and let the host decide exactly
+      const double prim = chk[CK_RP] / fmax(np_, 1e-10), dual = chk[CK_RD] / fmax(nd_, 1e-10);
+      const double nr = fmin(fmax(rho * sqrt(prim / fmax(dual, 1e-10)), 1e-6), 1e6);
+      if (nr * 1.0906 > rho * A.rho_tol || nr < 1.0906 * rho / A.rho_tol) { exit_code = EXIT_RHO; break; }
+    }
+  }
+  }  // batches
+
   if (!ok) {
-    if (threadIdx.x == 0) __hip_atomic_store(A.host_status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(A.host_status, (unsigned)EXIT_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(A.host_flag, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     return;  // nothing was written back: the state in global memory is the state before this launch
   }
   // ---- write the state back ---------------------------------------------------------------------------------------------------
@@ -414,7 +631,7 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
         A.zf[g] = z[d][t];
         A.yf[g] = y[d][t];
         A.fx[g] = fx[d][t];
-        if (A.emit_dy) A.dyf[g] = dy[d][t];
+        if (with_dy) A.dyf[g] = dy[d][t];
       }
     }
   }
@@ -431,14 +648,24 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
     if (!((e_code[e] >> 16) & 1)) {
       A.zc[e_row[e]] = e_z[e];
       A.yc[e_row[e]] = e_y[e];
+      if (with_dy) A.dyc[e_row[e]] = e_pp[(size_t)e * D];
     }
   }
   PSTAMP(8);
 #ifdef SCP_PHASE_PROFILE
   if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0)
-    for (int i = 0; i < 16; ++i) scp_persist_clk[i] = pacc[i];
+    for (int i = 0; i < 16; ++i) scp_persist_clk[i] = i == 15 ? (unsigned long long)steps : pacc[i];
 #endif
-  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(A.host_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // the nine check results in the slots the host reads (scp_qp::h_scal), then the exit code and the completion word
+    const int slot[NCHK] = {SL_RP, SL_NAX, SL_NZ, SL_RD, SL_NPX, SL_NATY, SL_NDY, SL_SUPP, SL_NATDY};
+#pragma unroll
+    for (int j = 0; j < NCHK; ++j)
+      __hip_atomic_store((u64*)(A.host_scal + slot[j]), (u64)__double_as_longlong(chk[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(A.host_status + 1, (unsigned)it_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(A.host_status, exit_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(A.host_flag, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // largest number of incidence-list entries of any block of `apb` consecutive agents -> out[0]
@@ -456,7 +683,7 @@ __global__ __launch_bounds__(256) void max_block_entries_kernel(int N, int K, in
 
 size_t persist_lds_bytes(int K, int D, int cap, int nblk) {
   const int apb = CB / D;
-  size_t dbl = (size_t)2 * CB * pad_col(K) + (size_t)apb * 64 * D + (size_t)2 * nblk + (size_t)cap * (4 * D + 4);
+  size_t dbl = (size_t)2 * CB * pad_col(K) + (size_t)apb * 64 * D + (size_t)NCHK * nblk + (size_t)cap * (4 * D + 4);
   size_t ints = (size_t)3 * cap + (size_t)apb * K + 1;
   return dbl * sizeof(double) + ((ints + 1) / 2 * 2) * sizeof(int);
 }
@@ -472,13 +699,17 @@ bool scp_qp_persist_eligible(const scp_qp* qp) {
   return nblk <= qp->ctx->n_cu;  // one workgroup per CU, all resident (grid-wide rendezvous)
 }
 
-// `nit` ADMM iterations in one launch.  Returns SCP_OK and *ran = 1 when the launch was enqueued (its completion status
-// arrives in qp->h_persist after the stream has drained: 1 done, 2 gave up -> the caller repeats the iterations on the
-// three-launch pipeline), *ran = 0 when this working set does not fit (nothing was enqueued).
-int scp_qp_cg1_persist(scp_qp* qp, int nit, bool emit_dy, int* ran) {
+// Run ADMM iterations from iteration count `it0` of the current solve in ONE launch, termination checks included, until
+// the kernel has something for the host to decide.  *ran = 0: this working set does not fit, nothing was enqueued.
+// Otherwise the call waits for the kernel's completion word (mapped host memory; the host spins instead of sleeping in
+// hipStreamSynchronize) and returns its exit code (*code; SCP_PERSIST_GAVE_UP: nothing was written back, the caller
+// repeats the iterations on the three-launch pipeline), the iteration count reached (*it_done) and, in qp->h_scal, the
+// nine results of the last check.
+int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   const QpDev& d = qp->d;
   scp_ctx* ctx = qp->ctx;
   hipStream_t s = ctx->stream;
+  const scp_qp_settings& st = qp->st;
   const int K = qp->K, D = qp->D;
   const int64_t C = qp->C, nx = (int64_t)K * C;
   const int apb = CB / D;
@@ -500,30 +731,41 @@ int scp_qp_cg1_persist(scp_qp* qp, int nit, bool emit_dy, int* ran) {
   }
   const size_t lds = persist_lds_bytes(K, D, qp->persist_cap, nblk);
   if (lds > 160 * 1024) return SCP_OK;  // too many rows around one block of agents: three-launch pipeline
+  const int budget = st.max_iter - it0;  // at most this many steps in this launch
   PersistArgs a;
-  a.K = K; a.N = qp->N; a.nblk = nblk; a.nit = nit; a.emit_dy = emit_dy ? 1 : 0; a.ent_cap = qp->persist_cap;
+  a.K = K; a.N = qp->N; a.nblk = nblk; a.ent_cap = qp->persist_cap;
+  a.it0 = it0; a.max_iter = st.max_iter; a.check_every = st.check_termination;
+  a.rho_interval = st.adaptive_rho_interval > 0 ? st.adaptive_rho_interval : 1;
   a.C = C;
-  a.rho = qp->rho; a.rho_c = qp->rho * qp->st.rho_col_scale; a.rho_eq = qp->st.rho_eq_scale; a.alpha = qp->st.alpha; a.h = qp->h;
+  a.rho = qp->rho; a.rho_c = qp->rho * st.rho_col_scale; a.rho_eq = st.rho_eq_scale; a.alpha = st.alpha; a.h = qp->h;
+  a.eps_abs = st.eps_abs; a.eps_rel = st.eps_rel; a.eps_prim_inf = st.eps_prim_inf;
+  a.rho_tol = (st.adaptive_rho && st.adaptive_rho_interval > 0) ? st.adaptive_rho_tolerance : 0.0;
   a.pMinv = d.pMinv;
   a.lf = d.lf; a.uf = d.uf; a.zf = d.zf; a.yf = d.yf; a.fx = d.fx; a.x = d.x;
   a.Qx = qp->qx_sel ? d.HQ : d.HQ + nx;
   a.dyf = d.dyf;
   a.cells = d.cells;
   a.gpart = d.gpart;
+  a.gcheck = d.gcheck;
   a.give_up = (unsigned*)d.sync_words;
   a.cell_ptr = d.cell_ptr; a.ent_code = d.ent_code; a.w_k = d.w_k; a.w_i = d.w_i; a.w_j = d.w_j;
   a.w_eta = d.w_eta; a.w_l = d.w_l; a.zc = d.zc; a.yc = d.yc; a.dyc = d.dyc; a.gval = d.gval;
   a.host_status = qp->h_persist_dev;
-  *qp->h_persist = 0u;
-  if (qp->persist_epoch == 0 || qp->persist_epoch + (u64)nit >= 0xFFFFFFF0ull) {
-    // first launch, the one after a give-up, or the step tags would wrap: every polled word starts from zero
+  a.host_scal = qp->h_scal_dev;
+  a.host_flag = (u64*)(qp->h_scal_dev + SL_COUNT + SCP_RESID_CAP);
+  a.seq = ++qp->check_seq;
+  qp->h_persist[0] = 0u;
+  qp->h_persist[1] = (unsigned)it0;
+  if (qp->persist_epoch == 0 || qp->persist_epoch + (u64)budget >= 0x7FFFFFF0ull) {
+    // first launch, the one after a give-up, or the step tags would reach bit 31 (reserved for the checks): every polled
+    // word starts from zero
     SCP_HIP_CHECK(ctx, hipMemsetAsync(d.sync_words, 0, 16, s));
     SCP_HIP_CHECK(ctx, hipMemsetAsync(d.cells, 0, (size_t)K * C * 2 * sizeof(u64), s));
     SCP_HIP_CHECK(ctx, hipMemsetAsync(d.gpart, 0, (size_t)SCP_GPART_WORDS * sizeof(u64), s));
+    SCP_HIP_CHECK(ctx, hipMemsetAsync(d.gcheck, 0, (size_t)SCP_GCHECK_WORDS * sizeof(u64), s));
     qp->persist_epoch = 0;
   }
   a.epoch0 = (unsigned)qp->persist_epoch;
-  qp->persist_epoch += (u64)nit;  // one tag per ADMM step
   if (D == 2) {
     if (lds > 64 * 1024)
       SCP_HIP_CHECK(ctx, scp_raise_lds_limit(ctx->device, reinterpret_cast<const void*>(cg1_persist_kernel<2>), lds));
@@ -535,6 +777,23 @@ int scp_qp_cg1_persist(scp_qp* qp, int nit, bool emit_dy, int* ran) {
   }
   SCP_HIP_CHECK(ctx, hipGetLastError());
   *ran = 1;
+  {
+    volatile u64* flag = (volatile u64*)(qp->h_scal + SL_COUNT + SCP_RESID_CAP);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (*flag != a.seq) {
+#if defined(__x86_64__) || defined(__i386__)
+      __builtin_ia32_pause();
+#endif
+      if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) break;
+    }
+    if (*flag != a.seq) SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // a fault surfaces here
+    if (*flag != a.seq) return scp_fail(ctx, SCP_ERR_HIP, "persistent kernel: completion word not written");
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
+  *code = (int)((volatile unsigned*)qp->h_persist)[0];
+  *it_done = (int)((volatile unsigned*)qp->h_persist)[1];
+  if (*code != SCP_PERSIST_GAVE_UP) qp->persist_epoch += (u64)(*it_done - it0);  // one tag per ADMM step
   return SCP_OK;
 }
 

@@ -37,8 +37,9 @@ def main():
         names = ["state load (once per launch)", "gather G, W', r: suffix scans", "p = Minv r (MFMA)",
                  "S0 p, F p: forward scans, publish cells", "rows: poll partner cells, eta . dS0p", "all-gather of the partials",
                  "step length", "updates (registers + entries)", "state write-back (once per launch)"]
-        steps = 25
-        print(f"cg1_persist_kernel, middle workgroup, last launch ({steps} steps assumed), us per step:")
+        steps = max(int(pb[15]), 1)
+        pb[15] = 0
+        print(f"cg1_persist_kernel, middle workgroup, last launch ({steps} steps incl. their termination checks), us per step:")
         for i, name in enumerate(names):
             v = pb[i] * 0.01
             print(f"  {name:44s} {v if i in (0, 8) else v / steps:8.2f} us{' (total)' if i in (0, 8) else ''}")

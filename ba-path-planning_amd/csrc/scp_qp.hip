@@ -471,6 +471,8 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.pS0t = c.take<double>(scp_packed_count(K, K));
   d.pHS = c.take<double>(scp_packed_count(2 * K, K));
   d.pMinv = c.take<double>(scp_packed_count(K, K));
+  d.T = c.take<double>((size_t)K * K);
+  d.pT = c.take<double>(scp_packed_count(K, K));
   const size_t nf = (size_t)Rf * C, nx = (size_t)K * C;
   d.lf = c.take<double>(nf);
   d.uf = c.take<double>(nf);
@@ -582,6 +584,8 @@ int build_kkt(scp_qp* qp) {
     hipLaunchKernelGGL(spd_inverse_kernel, dim3(1), dim3(1024), (size_t)3 * K * sizeof(double), s, K, d.aug, d.Minv);
   }
   QP_LAUNCHED(qp);
+  // T = S0 H_f^{-1}: the persistent kernel forms S0 p = T r on spare matrix-core waves next to p = H_f^{-1} r
+  QP_CHECK(scp_launch_gemm(qp->ctx, 1, K, K, K, 1.0, d.S0, d.Minv, 0.0, d.T));
   return scp_qp_pack_operands(qp);
 }
 

@@ -1410,7 +1410,7 @@ struct PackDesc {
   int R, M;
 };
 struct PackArgs {
-  PackDesc m[6];
+  PackDesc m[7];
 };
 __global__ __launch_bounds__(256) void pack_operands_kernel(PackArgs a) {
   const PackDesc d = a.m[blockIdx.y];
@@ -1436,7 +1436,8 @@ int scp_qp_pack_operands(scp_qp* qp) {
   a.m[3] = {d.S0t, d.pS0t, K, K};
   a.m[4] = {d.HS, d.pHS, 2 * K, K};
   a.m[5] = {d.Minv, d.pMinv, K, K};
-  hipLaunchKernelGGL(pack_operands_kernel, dim3(16, 6), dim3(256), 0, qp->ctx->stream, a);
+  a.m[6] = {d.T, d.pT, K, K};
+  hipLaunchKernelGGL(pack_operands_kernel, dim3(16, 7), dim3(256), 0, qp->ctx->stream, a);
   FUSED_LAUNCHED(qp);
   return SCP_OK;
 }

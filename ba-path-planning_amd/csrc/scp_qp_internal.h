@@ -19,6 +19,7 @@ struct QpDev {
   // [row tile][k step][lane] = A[16 tile + (lane & 15)][4 step + (lane >> 4)], zero beyond the matrix, so that one
   // wave-wide operand load is 512 contiguous bytes
   double *pF, *pFt, *pS0, *pS0t, *pHS, *pMinv;
+  double *T, *pT;  // T = S0 H_f^{-1} (K x K, rebuilt with H_f^{-1}) and its packed form: S0 p = T r without waiting for p
   // fixed rows
   double *lf, *uf, *zf, *yf, *wf, *tf;
   // x-space vectors [K][C]

@@ -54,6 +54,7 @@ struct PersistArgs {
   double rho, rho_c, rho_eq, alpha, h;
   double eps_abs, eps_rel, eps_prim_inf, rho_tol;  // termination tests (eps_prim_inf <= 0: no certificate; rho_tol <= 0: fixed rho)
   const double* pMinv;
+  const double* pT;      // packed T = S0 H_f^{-1}
   const double *lf, *uf;
   double *zf, *yf, *fx, *x, *Qx, *dyf;
   u64* cells;       // [K][N][D][2] granules: S0 p of (time step, agent), low / high word, each tagged with the step
@@ -75,12 +76,34 @@ enum { EXIT_SOLVED = 1, EXIT_GAVE_UP = 2, EXIT_MAX_ITER = 3, EXIT_INFEASIBLE = 4
 constexpr int NCHK = 9;  // rp, |Ax|, |z|, rd, |Px|, |A^T y|, |dy|, supp (a sum), |A^T dy|  (maxima of non-negative values)
 constexpr int CK_RP = 0, CK_NAX = 1, CK_NZ = 2, CK_RD = 3, CK_NPX = 4, CK_NATY = 5, CK_NDY = 6, CK_SUPP = 7, CK_NATDY = 8;
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// One double = one 16-byte pair of granules {low word, tag, high word, tag}: ONE write-through store, ONE load (a scalar
+// sc1 store is one fabric write whatever its width: 8-byte stores doubled the hand-off's fabric traffic).  Each 8-byte
+// half carries its own tag, so a torn pair is detected like a late one.  Inline asm because the builtins offer no 16-byte
+// agent-scope access; the asm loads wait for their own data (the compiler does not count them).
 __device__ inline void st_granules(u64* g, unsigned tag, double v) {
-  const u64 t = (u64)tag << 32;
-  __hip_atomic_store(g, t | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(g + 1, t | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const u32x4 w = {(unsigned)__double2loint(v), tag, (unsigned)__double2hiint(v), tag};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g), "v"(w) : "memory");
 }
-__device__ inline u64 ld_granule(const u64* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline u32x4 ld_pair(const u64* g) {
+  u32x4 w;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(g) : "memory");
+  return w;
+}
+template <int D>
+__device__ inline void ld_cell(const u64* g, u32x4 (&w)[D]) {  // the D doubles of one cell: D loads in flight, one wait
+  if (D == 2) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1])
+                 : "v"(g)
+                 : "memory");
+  } else {
+#pragma unroll
+    for (int d = 0; d < D; ++d) w[d] = ld_pair(g + 2 * d);
+  }
+}
+__device__ inline bool pair_ok(const u32x4& w, unsigned tag) { return w[1] == tag && w[3] == tag; }
+__device__ inline double pair_value(const u32x4& w) { return __hiloint2double((int)w[2], (int)w[0]); }
 
 template <int D>
 __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs A) {
@@ -95,7 +118,8 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
   const int cap = A.ent_cap;
   double* Rt = lds;                        // [16][RSK]   r, MFMA B operand
   double* Pt = Rt + CB * RSK;              // [16][RSK]   p
-  double* Qt = Pt + CB * RSK;              // [APB][64][D] own S0 p cells
+  double* Tt = Pt + CB * RSK;              // [16][RSK]   S0 p = T r (when the workgroup has waves to spare for it)
+  double* Qt = Tt + CB * RSK;              // [APB][64][D] own S0 p cells
   double* gp = Qt + APB * 64 * D;          // [nblk][9]   all-gathered partials (line search: 2 per workgroup; check: 9)
   double* e_c = gp + NCHK * A.nblk;        // [cap][D] signed eta (+ on agent i's side, - on agent j's)
   double* e_l = e_c + (size_t)cap * D;     // [cap] lower bound
@@ -183,8 +207,11 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
       qx[d] = A.Qx[g];
     }
   }
+  // waves [0, tK): tiles of p = H_f^{-1} r; waves [tK, 2 tK), when the workgroup has them: tiles of S0 p = T r, so the cells
+  // can be published one scan phase earlier (the hand-off then overlaps the F p scans)
+  const bool use_T = APB >= 2 * tK;
   double aM[CHB];
-  tile_prefetch<CHB>(A.pMinv, nks, wave < tK ? wave : 0, 0, nks, aM);
+  tile_prefetch<CHB>(use_T && wave >= tK ? A.pT : A.pMinv, nks, wave < tK ? wave : (use_T && wave < 2 * tK ? wave - tK : 0), 0, nks, aM);
   __syncthreads();
   // incidence-list range of this lane's cell (time step k of this wave's agent); cells without entries publish nothing
   const int c0 = aok ? cptr[wave * K + min(k, K - 1)] : 0;
@@ -238,8 +265,10 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
     __syncthreads();
     PSTAMP(1);
     // ---- p = H_f^{-1} r on the matrix cores: one 16-row tile per wave --------------------------------------------
-    if (wave < tK) {
+    if (wave < tK || (use_T && wave < 2 * tK)) {
       const int li = lane & 15, lk = lane >> 4;
+      const int tile = wave < tK ? wave : wave - tK;
+      double* Ot = wave < tK ? Pt : Tt;
       double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int s = 0; s < CHB; ++s) {  // K <= 64: the whole operand row block is resident in aM
@@ -251,8 +280,8 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int row = wave * 16 + lk + 4 * q;
-        if (row < K) Pt[li * RSK + row] = acc[q];
+        const int row = tile * 16 + lk + 4 * q;
+        if (row < K) Ot[li * RSK + row] = acc[q];
       }
     }
     __syncthreads();
@@ -260,6 +289,16 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
     // ---- S0 p, F p (forward scans), r.p; publish the S0 p cells that have rows -----------------------------------------
     double p[D], qp[D], fp[D][4];
     double rz = 0.0;
+    if (use_T) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        qp[d] = live ? Tt[(wave * D + d) * RSK + k] : 0.0;
+        if (c1 > c0) {
+          st_granules(my_cell + 2 * d, tag, qp[d]);
+          Qt[(wave * 64 + k) * D + d] = qp[d];
+        }
+      }
+    }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       p[d] = live ? Pt[(wave * D + d) * RSK + k] : 0.0;
@@ -268,12 +307,12 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
       const double cs2 = lane_below(wave_incl_sum(cs1));
       const double cs1p = lane_below(cs1);
       const double pn = lane_above(p[d]);
-      qp[d] = hh * (cs2 - 0.5 * cs1p);
+      if (!use_T) qp[d] = hh * (cs2 - 0.5 * cs1p);
       fp[d][0] = (live && k < K - 1) ? (pn - p[d]) / h : 0.0;
       fp[d][1] = p[d];
       fp[d][2] = live ? h * cs1 : 0.0;  // lanes beyond the horizon hold the running totals: keep their rows at zero,
       fp[d][3] = live ? hh * (cs2 + 0.5 * cs1) : 0.0;  // or the next step's suffix sums would pick them up
-      if (c1 > c0) {
+      if (!use_T && c1 > c0) {
         st_granules(my_cell + 2 * d, tag, qp[d]);
         Qt[(wave * 64 + k) * D + d] = qp[d];
       }
@@ -291,14 +330,12 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
         const int code = e_code[e];
         const int ek = code & 0xFF, al = (code >> 8) & 0xFF, side = (code >> 16) & 1;
         const u64* pc = A.cells + e_pad[e];
-        u64 w[2 * D];
+        u32x4 w[D];
         for (;;) {
+          ld_cell<D>(pc, w);
           bool valid = true;
 #pragma unroll
-          for (int q = 0; q < 2 * D; ++q) {
-            w[q] = ld_granule(pc + q);
-            valid = valid && (unsigned)(w[q] >> 32) == tag;
-          }
+          for (int d = 0; d < D; ++d) valid = valid && pair_ok(w[d], tag);
           if (valid) break;
           if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
                                        __hip_atomic_load(A.give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
@@ -311,7 +348,7 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
         double s = 0.0;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-          const double pp = __hiloint2double((int)(unsigned)w[2 * d + 1], (int)(unsigned)w[2 * d]);
+          const double pp = pair_value(w[d]);
           e_pp[(size_t)e * D + d] = pp;
           s += e_c[(size_t)e * D + d] * (Qt[(al * 64 + ek) * D + d] - pp);
         }
@@ -338,11 +375,10 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
       unsigned spins = 0;
       bool bad = false;
       for (int q = threadIdx.x; q < 2 * nblk; q += NT) {  // one double (two granules) per thread and pass
-        u64 w0, w1;
+        u32x4 w;
         for (;;) {
-          w0 = ld_granule(gpart + 2 * q);
-          w1 = ld_granule(gpart + 2 * q + 1);
-          if ((unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag) break;
+          w = ld_pair(gpart + 2 * q);
+          if (pair_ok(w, tag)) break;
           if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
                                        __hip_atomic_load(A.give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
             bad = true;
@@ -351,7 +387,7 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
           __builtin_amdgcn_s_sleep(1);
         }
         if (bad) break;
-        gp[q] = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
+        gp[q] = pair_value(w);
       }
       if (bad) {
         __hip_atomic_store(A.give_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -507,14 +543,12 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
         const int code = e_code[e];
         const int ek = code & 0xFF, al = (code >> 8) & 0xFF, side = (code >> 16) & 1;
         const u64* pc = A.cells + e_pad[e];
-        u64 w[2 * D];
+        u32x4 w[D];
         for (;;) {
+          ld_cell<D>(pc, w);
           bool valid = true;
 #pragma unroll
-          for (int q = 0; q < 2 * D; ++q) {
-            w[q] = ld_granule(pc + q);
-            valid = valid && (unsigned)(w[q] >> 32) == ctag;
-          }
+          for (int d = 0; d < D; ++d) valid = valid && pair_ok(w[d], ctag);
           if (valid) break;
           if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
                                        __hip_atomic_load(A.give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
@@ -527,7 +561,7 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
         double ax = 0.0;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-          const double qq = __hiloint2double((int)(unsigned)w[2 * d + 1], (int)(unsigned)w[2 * d]);
+          const double qq = pair_value(w[d]);
           const double qo = Qt[(al * 64 + ek) * D + d];
           e_qo[(size_t)e * D + d] = qo;
           e_qp[(size_t)e * D + d] = qq;
@@ -567,11 +601,10 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
       unsigned spins = 0;
       bool bad = false;
       for (int q = threadIdx.x; q < NCHK * nblk; q += NT) {
-        u64 w0, w1;
+        u32x4 w;
         for (;;) {
-          w0 = ld_granule(A.gcheck + 2 * q);
-          w1 = ld_granule(A.gcheck + 2 * q + 1);
-          if ((unsigned)(w0 >> 32) == ctag && (unsigned)(w1 >> 32) == ctag) break;
+          w = ld_pair(A.gcheck + 2 * q);
+          if (pair_ok(w, ctag)) break;
           if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
                                        __hip_atomic_load(A.give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
             bad = true;
@@ -580,7 +613,7 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
           __builtin_amdgcn_s_sleep(1);
         }
         if (bad) break;
-        gp[q] = __hiloint2double((int)(unsigned)w1, (int)(unsigned)w0);
+        gp[q] = pair_value(w);
       }
       if (bad) {
         __hip_atomic_store(A.give_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -683,7 +716,7 @@ __global__ __launch_bounds__(256) void max_block_entries_kernel(int N, int K, in
 
 size_t persist_lds_bytes(int K, int D, int cap, int nblk) {
   const int apb = CB / D;
-  size_t dbl = (size_t)2 * CB * pad_col(K) + (size_t)apb * 64 * D + (size_t)NCHK * nblk + (size_t)cap * (4 * D + 4);
+  size_t dbl = (size_t)3 * CB * pad_col(K) + (size_t)apb * 64 * D + (size_t)NCHK * nblk + (size_t)cap * (4 * D + 4);
   size_t ints = (size_t)3 * cap + (size_t)apb * K + 1;
   return dbl * sizeof(double) + ((ints + 1) / 2 * 2) * sizeof(int);
 }
@@ -741,6 +774,7 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   a.eps_abs = st.eps_abs; a.eps_rel = st.eps_rel; a.eps_prim_inf = st.eps_prim_inf;
   a.rho_tol = (st.adaptive_rho && st.adaptive_rho_interval > 0) ? st.adaptive_rho_tolerance : 0.0;
   a.pMinv = d.pMinv;
+  a.pT = d.pT;
   a.lf = d.lf; a.uf = d.uf; a.zf = d.zf; a.yf = d.yf; a.fx = d.fx; a.x = d.x;
   a.Qx = qp->qx_sel ? d.HQ : d.HQ + nx;
   a.dyf = d.dyf;

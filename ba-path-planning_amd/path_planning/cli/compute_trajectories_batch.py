@@ -53,8 +53,13 @@ def make_scenario(N, cfg, seed=None):
     return init_pos, final_pos, cfg["space_dims"]
 
 
-def run_single_trial(N, cfg, rng=None, seed=None, device=None, scenario=None, save_path=None):
-    """One SCP solve for N vehicles -> result record (compute_trajectories_batch.py:28-67)."""
+def run_single_trial(N, cfg, rng=None, seed=None, device=None, scenario=None, save_path=None, pool=None):
+    """One SCP solve for N vehicles -> result record (compute_trajectories_batch.py:28-67).
+
+    pool: a dict owned by the calling worker (one per thread / stream).  The reference builds a new solver per trial
+    (:32-38); here building one -- context, pinned buffers, the QP workspace -- costs more than solving ~100 agents, so
+    a worker keeps its solver per problem shape and hands it the next scenario (identical results: every solve starts
+    from set_problem / reset)."""
     init_pos, final_pos, space = scenario if scenario is not None else make_scenario(N, cfg, seed)
     solver = None
     t0 = time.perf_counter()
@@ -62,16 +67,23 @@ def run_single_trial(N, cfg, rng=None, seed=None, device=None, scenario=None, sa
     err_msg = None
     iters = None
     try:
-        solver = SCP(
-            n_vehicles=N,
-            time_horizon=cfg["time_horizon"],
-            time_step=cfg["time_step"],
-            min_distance=cfg["min_distance"],
-            space_dims=space,
-            dim=cfg.get("dim", 2),
-            device=device,
-            verbose=cfg.get("verbose", False),
-        )
+        key = (N, cfg["time_horizon"], cfg["time_step"], cfg["min_distance"], cfg.get("dim", 2), device)
+        solver = pool.get(key) if pool is not None else None
+        if solver is None:
+            solver = SCP(
+                n_vehicles=N,
+                time_horizon=cfg["time_horizon"],
+                time_step=cfg["time_step"],
+                min_distance=cfg["min_distance"],
+                space_dims=space,
+                dim=cfg.get("dim", 2),
+                device=device,
+                verbose=cfg.get("verbose", False),
+            )
+            if pool is not None:
+                pool[key] = solver
+        else:
+            solver.set_space_dims(space)
         solver.set_initial_states(init_pos)
         solver.set_final_states(final_pos)
         t0 = time.perf_counter()
@@ -168,6 +180,8 @@ def build_parser():
     p.add_argument("--max-iterations", type=int, default=None)
     p.add_argument("--save-trajectories", action="store_true",
                    help="write <results-dir>/trajectory_N<N>_t<trial>.npz (positions, velocities, accelerations) per run")
+    p.add_argument("--fresh-solvers", action="store_true",
+                   help="build a new solver object for every trial like the reference (:32-38) instead of reusing one per worker")
     p.add_argument("--validate", action="store_true", help="add the minimum pair distance of every result to its record")
     p.add_argument("--streams", type=int, default=1,
                    help="solve this many scenarios concurrently on one GPU, each on its own HIP stream (a solve of "
@@ -227,11 +241,18 @@ def main(argv=None):
         scenarios[(N, trial)] = make_scenario(N, cfg, seed)
     t_gen = time.perf_counter() - t_gen
 
+    import threading
+
+    pools = threading.local()  # one solver pool per worker thread (= per HIP stream)
+
     def one_job(job):
         N, trial = job
         seed = trial_seed(cfg, N, trial)
         save = str(Path(cfg["results_dir"]) / f"trajectory_N{N}_t{trial}.npz") if args.save_trajectories else None
-        res = run_single_trial(N, cfg, rng=np.random, seed=seed, device=local_rank, scenario=scenarios[job], save_path=save)
+        if not hasattr(pools, "solvers"):
+            pools.solvers = {}
+        res = run_single_trial(N, cfg, rng=np.random, seed=seed, device=local_rank, scenario=scenarios[job], save_path=save,
+                               pool=None if args.fresh_solvers else pools.solvers)
         res["trial_index"] = trial
         status_str = "OK" if res["status"] == "success" else f"ERR ({res['error']})"
         print(f"  [rank {rank}] N={N} trial {trial+1:02d}/{cfg['trials_per_N']}  time = {res['time_sec']:.3f}s  [{status_str}]")

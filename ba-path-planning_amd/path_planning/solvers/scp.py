@@ -110,6 +110,17 @@ class SCP:
         if self.verbose and self.shard.rank == 0:
             print(*a)
 
+    def set_space_dims(self, space_dims):
+        """Change the workspace box of an existing solver (same N, T, h, R, dim).  Together with set_initial_states /
+        set_final_states this lets one solver object -- its context, streams, pinned buffers and the QP workspace, whose
+        creation costs more than a 100-agent solve -- be reused for the next scenario (compute-trajectories-batch)."""
+        if len(space_dims) != 2 * self.D:
+            raise ValueError(f"space_dims needs {2 * self.D} entries [min..., max...]")
+        self.space_dims = space_dims
+        self.pos_min = np.array(space_dims[: self.D])
+        self.pos_max = np.array(space_dims[self.D:])
+        self.trajectories = None
+
     # ------------------------------------------------------------------------------------------------
     # a0: states (scp.py:99-129)
     # ------------------------------------------------------------------------------------------------

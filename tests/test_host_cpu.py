@@ -107,7 +107,7 @@ def test_batch_cli_schema(tmp_path, monkeypatch):
 
     from path_planning.cli import compute_trajectories_batch as cli
 
-    def fake_trial(N, cfg, rng=None, seed=None, device=None, scenario=None, save_path=None):
+    def fake_trial(N, cfg, rng=None, seed=None, device=None, scenario=None, save_path=None, pool=None):
         assert scenario is not None and scenario[0].shape == (N, 2)  # generated before the timed loop
         return {"N": N, "status": "success" if seed % 2 == 0 else "error", "time_sec": 0.1 * N + 0.01 * (seed % 7),
                 "error": None if seed % 2 == 0 else "boom", "K": 50, "T": cfg["time_horizon"], "h": cfg["time_step"],

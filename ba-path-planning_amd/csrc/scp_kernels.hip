@@ -371,11 +371,16 @@ constexpr int PAIR_STEPS = 16;                             // steps per thread, 
 // L1/L2 path runs 1.63 ms at 4096 x 50, with 2 steps 2.16 ms)
 template <bool USE_LDS, int MODE>
 struct PairUnroll {
-  static constexpr int value = (USE_LDS && MODE != 2 /* MODE_VIOLATIONS */) ? 2 : 4;
+  static constexpr int value = (USE_LDS && MODE != 2 /* MODE_VIOLATIONS: streaming reads, 4 in flight */) ? 2 : 4;
 };
 constexpr int PAIR_ROWS = PAIR_THREADS * PAIR_STEPS * 2;   // rows (= pairs at one k) per workgroup
 
-enum PairMode { MODE_LINEARIZE = 0, MODE_CHECK = 1, MODE_VIOLATIONS = 2 };
+enum PairMode { MODE_LINEARIZE = 0, MODE_CHECK = 1, MODE_VIOLATIONS = 2, MODE_VIOL_RECOMPUTE = 3 };
+// MODE_VIOL_RECOMPUTE: the violations pass without the 8 (D + 1) bytes-per-row read-back: eta and R - dist are
+// recomputed from the slice of the linearisation point (P_tm) exactly as the linearise pass computed them, and
+//   l_r - (A x)_r = (R - dist) + eta.(Q_prev_i - Q_prev_j) - eta.(Q_new_i - Q_new_j) = (R - dist) - eta.(dP_i - dP_j),
+// dP = P_new - P_prev (the free motion c cancels): Q_tm holds dP.  Same LDS footprint as the linearise pass, no HBM
+// stream at all.
 
 struct PairArgs {
   int N, K, D;
@@ -476,6 +481,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
   const int64_t c0 = (int64_t)blockIdx.x * PAIR_ROWS - par;  // first local pair offset of this workgroup
   constexpr bool NEED_P = MODE != MODE_VIOLATIONS;
   constexpr bool NEED_Q = MODE != MODE_CHECK;
+  constexpr bool VIOL = MODE == MODE_VIOLATIONS || MODE == MODE_VIOL_RECOMPUTE;  // selects violated rows, reduces max violation
 
   const double* P = NEED_P ? a.P_tm + (int64_t)k * N * D : nullptr;
   const double* Q = NEED_Q ? a.Q_tm + (int64_t)k * N * D : nullptr;
@@ -554,6 +560,13 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
       }
     }
     uint32_t marked[PAIR_UNROLL];
+    if (MODE == MODE_VIOL_RECOMPUTE) {
+#pragma unroll
+      for (int u = 0; u < PAIR_UNROLL; ++u) {
+        const int64_t lrA = slice0 + off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS);
+        marked[u] = (valid[u][0] || valid[u][1]) ? (a.bitmap[(lrA + (valid[u][0] ? 0 : 1)) >> 5] >> (lrA & 31)) & 3u : 0u;
+      }
+    }
     if (MODE == MODE_VIOLATIONS) {  // streaming reads of the compact rows, all issued before use
 #pragma unroll
       for (int u = 0; u < PAIR_UNROLL; ++u) {
@@ -601,7 +614,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
           const double inv = rsqrt_nr(fmax(ss, 1e-200));
           double raw = ss * inv;
           raw = fma(fma(-raw, raw, ss), 0.5 * inv, raw);  // one correction step: sqrt to < 1 ulp (0 stays 0)
-          if (valid[u][e]) {
+          if (MODE != MODE_VIOL_RECOMPUTE && valid[u][e]) {
             my_min = fmin(my_min, raw);
             if (raw < thr) {
               const int64_t off = off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS) + e;
@@ -623,6 +636,19 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
             // reference's eta.diff term is kept for the degenerate rule (there eta.diff != dist)
             l_v[u][e] = (a.R - dist) + qd;
             sel[u][e] = valid[u][e] && ((dist - a.R) < a.margin);
+          }
+          if (MODE == MODE_VIOL_RECOMPUTE) {
+            const Pt<D> Di = load_pt<D>(Q, i), Dj = load_pt<D>(Q, j);  // dP = P_new - P_prev
+            const double dist = deg ? 1.0 : raw;
+            double qd = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+              const double e_d = deg ? (d == 0 ? 1.0 : 0.0) : diff[d] * inv;
+              qd = fma(e_d, Di.v[d] - Dj.v[d], qd);
+            }
+            const double viol = (a.R - dist) - qd;  // l_r - (A x)_r
+            if (valid[u][e]) my_maxv = fmax(my_maxv, viol);
+            sel[u][e] = valid[u][e] && (viol > a.margin) && !((marked[u] >> e) & 1u);
           }
         } else {
           const Pt<D> Qi = load_pt<D>(Q, i), Qj = load_pt<D>(Q, j);
@@ -689,19 +715,19 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
   // microsecond chip-wide, 25 600 of them (one per wave) would cost more than the whole streaming pass.
   __shared__ double red_d[PAIR_THREADS / 64];
   __shared__ unsigned long long red_u[PAIR_THREADS / 64];
-  if (MODE != MODE_VIOLATIONS) {
+  if (!VIOL) {
     my_min = wave_min(my_min);
     my_first = wave_min_u64(my_first);
   } else {
     my_maxv = wave_max(my_maxv);
   }
   if ((threadIdx.x & 63) == 63) {
-    red_d[threadIdx.x >> 6] = MODE != MODE_VIOLATIONS ? my_min : my_maxv;
+    red_d[threadIdx.x >> 6] = !VIOL ? my_min : my_maxv;
     red_u[threadIdx.x >> 6] = my_first;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (MODE != MODE_VIOLATIONS) {
+    if (!VIOL) {
       double m = red_d[0];
       unsigned long long f = red_u[0];
 #pragma unroll
@@ -741,6 +767,23 @@ static int ensure_tm(scp_ctx* ctx, size_t bytes) {
   return SCP_OK;
 }
 
+// [N][K][D] -> time-major P_prev and dP = P_new - P_prev (MODE_VIOL_RECOMPUTE)
+__global__ __launch_bounds__(256) void pair_prep_delta_kernel(int N, int K, int D, const double* __restrict__ pos_prev,
+                                                               const double* __restrict__ pos_new,
+                                                               double* __restrict__ P_tm, double* __restrict__ dP_tm) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t C = (int64_t)N * D;
+  if (t >= C * K) return;
+  const int k = (int)(t / C);
+  const int c = (int)(t % C);
+  const int i = c / D, d = c % D;
+  const int64_t g = ((int64_t)i * K + k) * D + d;
+  const double pp = pos_prev[g];
+  P_tm[t] = pp;
+  dP_tm[t] = pos_new[g] - pp;
+}
+
+// MODE_VIOL_RECOMPUTE: pos_ref_layout = the linearisation point, p0 = the new positions (v0 unused)
 template <int MODE>
 static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_layout, const double* p0,
                             const double* v0) {
@@ -751,13 +794,17 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
   if (rc) return rc;
   double* P_tm = MODE != MODE_VIOLATIONS ? ctx->tm_scratch : nullptr;
   double* Q_tm = MODE != MODE_CHECK ? ctx->tm_scratch + slice : nullptr;
-  hipLaunchKernelGGL(pair_prep_kernel, dim3(scp_cdiv((int64_t)N * K * D, 256)), dim3(256), 0, ctx->stream, N, K, D,
-                     a.h, pos_ref_layout, p0, v0, P_tm, Q_tm);
+  if (MODE == MODE_VIOL_RECOMPUTE)
+    hipLaunchKernelGGL(pair_prep_delta_kernel, dim3(scp_cdiv((int64_t)N * K * D, 256)), dim3(256), 0, ctx->stream, N, K, D,
+                       pos_ref_layout, p0, P_tm, Q_tm);
+  else
+    hipLaunchKernelGGL(pair_prep_kernel, dim3(scp_cdiv((int64_t)N * K * D, 256)), dim3(256), 0, ctx->stream, N, K, D,
+                       a.h, pos_ref_layout, p0, v0, P_tm, Q_tm);
   a.P_tm = P_tm;
   a.Q_tm = Q_tm;
   hipLaunchKernelGGL(pair_stats_init_kernel, dim3(1), dim3(1), 0, ctx->stream, a.stats);
   if (nq <= 0) return SCP_OK;
-  const size_t lds_bytes = (size_t)(MODE == MODE_LINEARIZE ? 2 : 1) * N * D * sizeof(double);
+  const size_t lds_bytes = (size_t)((MODE == MODE_LINEARIZE || MODE == MODE_VIOL_RECOMPUTE) ? 2 : 1) * N * D * sizeof(double);
   // the k-slice must start 16-byte aligned in global memory for the double2 staging loads: N*D even
 #ifdef SCP_PHASE_PROFILE  // developer build only (make prof): ablation switch of tools/pair_bench.py
   const char* abl = getenv("SCP_PAIR_ABLATE");
@@ -852,12 +899,16 @@ __global__ __launch_bounds__(CMP_THREADS) void compact_scan_kernel(uint32_t* __r
   if (threadIdx.x == 0) stats->n_selected = (unsigned long long)carry;
 }
 
-// write the global row id of every set bit; optionally merge the map into `merge_into` and clear it
+// write the global row id of every set bit; optionally merge the map into `merge_into` and clear it.  When the list
+// is too short for a merging pass (stats->n_selected > cap, written by compact_scan_kernel) nothing is merged: the
+// scratch map is cleared and the caller repeats the pass with a longer list from an unchanged working-set bitmap.
 __global__ __launch_bounds__(CMP_THREADS) void compact_write_kernel(uint32_t* __restrict__ map, int64_t words,
                                                                      const uint32_t* __restrict__ block_off, int64_t nq,
                                                                      int64_t q_begin, int64_t pairs,
                                                                      int64_t* __restrict__ rows, int64_t cap,
-                                                                     uint32_t* __restrict__ merge_into) {
+                                                                     uint32_t* __restrict__ merge_into,
+                                                                     const scp_pair_stats* __restrict__ stats) {
+  const bool overflow = merge_into != nullptr && stats->n_selected > (unsigned long long)cap;
   const int64_t w0 = (int64_t)blockIdx.x * CMP_WORDS + (int64_t)threadIdx.x * CMP_WPT;
   uint32_t wd[CMP_WPT];
   int c = 0;
@@ -873,14 +924,14 @@ __global__ __launch_bounds__(CMP_THREADS) void compact_write_kernel(uint32_t* __
   for (int i = 0; i < CMP_WPT; ++i) {
     uint32_t m = wd[i];
     if (m && merge_into) {
-      merge_into[w0 + i] |= m;
+      if (!overflow) merge_into[w0 + i] |= m;
       map[w0 + i] = 0u;
     }
     while (m) {
       const int bit = __ffs((int)m) - 1;
       m &= m - 1;
       const int64_t lr = (w0 + i) * 32 + bit;
-      if (slot < cap) rows[slot] = (lr / nq) * pairs + q_begin + (lr % nq);
+      if (!overflow && slot < cap) rows[slot] = (lr / nq) * pairs + q_begin + (lr % nq);
       ++slot;
     }
   }
@@ -920,7 +971,7 @@ static int launch_compaction(scp_ctx* ctx, uint32_t* map, int64_t words, int64_t
   hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(CMP_THREADS), 0, ctx->stream, map, words, ctx->cmp_tot);
   hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(CMP_THREADS), 0, ctx->stream, ctx->cmp_tot, nblocks, stats);
   hipLaunchKernelGGL(compact_write_kernel, dim3(nblocks), dim3(CMP_THREADS), 0, ctx->stream, map, words, ctx->cmp_tot,
-                     nq, q_begin, pairs, rows, cap, merge_into);
+                     nq, q_begin, pairs, rows, cap, merge_into, stats);
   SCP_HIP_CHECK(ctx, hipGetLastError());
   return SCP_OK;
 }
@@ -999,6 +1050,30 @@ extern "C" int scp_collision_violations(scp_ctx* ctx, int N, int K, int D, doubl
   rc = launch_pair_pass<MODE_VIOLATIONS>(ctx, a, pos, p0, v0);
   if (rc) return rc;
   // new rows = bits of the scratch map; merging them into the working-set bitmap also clears the scratch map
+  return launch_compaction(ctx, ctx->cmp_map, words, nq, q_begin, a.pairs, new_rows, new_cap, sel_bitmap, stats);
+}
+
+extern "C" int scp_collision_violations_at(scp_ctx* ctx, int N, int K, int D, double R, int64_t q_begin, int64_t q_end,
+                                           const double* pos_prev, const double* pos_new, double feas_tol,
+                                           int64_t* new_rows, int64_t new_cap, uint32_t* sel_bitmap,
+                                           scp_pair_stats* stats) {
+  if (!ctx) return SCP_ERR_INVALID;
+  int rc = check_pair_range(ctx, N, K, D, q_begin, q_end);
+  if (rc) return rc;
+  SCP_REQUIRE(ctx, pos_prev && pos_new && sel_bitmap && stats && (new_rows || new_cap == 0),
+              "collision_violations_at: null pointer");
+  PairArgs a{};
+  a.N = N; a.K = K; a.D = D; a.R = R; a.h = 0.0;
+  a.q_begin = q_begin; a.q_end = q_end; a.pairs = scp_pairs(N);
+  a.margin = feas_tol;
+  const int64_t nq = q_end - q_begin;
+  const int64_t words = (K * nq + 31) / 32;
+  rc = ensure_cmp(ctx, words);
+  if (rc) return rc;
+  a.bitmap = sel_bitmap; a.mark = ctx->cmp_map; a.stats = stats;
+  a.eta_stride = scp_eta_stride(K, nq);
+  rc = launch_pair_pass<MODE_VIOL_RECOMPUTE>(ctx, a, pos_prev, pos_new, nullptr);
+  if (rc) return rc;
   return launch_compaction(ctx, ctx->cmp_map, words, nq, q_begin, a.pairs, new_rows, new_cap, sel_bitmap, stats);
 }
 

@@ -58,7 +58,7 @@ EXPORTS = [
     "scp_abi_version", "scp_ctx_create", "scp_ctx_destroy", "scp_last_error", "scp_ctx_synchronize",
     "scp_ctx_last_pair_ms",
     "scp_kinematics", "scp_fixed_bounds", "scp_linearize_pairs", "scp_check_avoidance",
-    "scp_collision_violations", "scp_gather_rows", "scp_rel_step", "scp_qp_default_settings",
+    "scp_collision_violations", "scp_collision_violations_at", "scp_gather_rows", "scp_rel_step", "scp_qp_default_settings",
     "scp_qp_workspace_bytes", "scp_qp_create", "scp_qp_destroy", "scp_qp_update_settings", "scp_qp_set_problem",
     "scp_qp_reset", "scp_qp_add_rows", "scp_qp_solve", "scp_qp_clone_state", "scp_qp_get_solution",
     "scp_qp_get_duals", "scp_gemm_f64", "scp_qp_peek",
@@ -98,6 +98,7 @@ def load_library():
     lib.scp_linearize_pairs.argtypes = [vp, i32, i32, i32, f64, f64, i64, i64, vp, vp, vp, vp, vp, f64, vp, i64, vp, vp]
     lib.scp_check_avoidance.argtypes = [vp, i32, i32, i32, f64, i64, i64, vp, vp]
     lib.scp_collision_violations.argtypes = [vp, i32, i32, i32, f64, i64, i64, vp, vp, vp, vp, vp, f64, vp, i64, vp, vp]
+    lib.scp_collision_violations_at.argtypes = [vp, i32, i32, i32, f64, i64, i64, vp, vp, f64, vp, i64, vp, vp]
     lib.scp_gather_rows.argtypes = [vp, i32, i32, i32, i64, i64, vp, vp, vp, i64, vp, vp]
     lib.scp_rel_step.argtypes = [vp, i64, vp, vp, pd]
     lib.scp_qp_default_settings.argtypes = [C.POINTER(QpSettings)]
@@ -259,6 +260,7 @@ class PairPass:
         self.sel_cap = int(sel_cap if sel_cap is not None else min(max(self.rows, 1), max(65536, 64 * N * K)))
         self.sel = torch.empty(self.sel_cap, dtype=torch.int64, device=ctx.tdev)
         self.last_linearize_ms = self.last_violations_ms = 0.0
+        self.pos_prev = None  # linearisation point of the stored rows (kept for the recomputing violations pass)
 
     def _grow(self, need):
         torch = _torch()
@@ -276,24 +278,33 @@ class PairPass:
             min_dist, first, n_sel, _ = c.read_stats()
             self.last_linearize_ms = c.last_pair_ms() if self.nq > 0 else 0.0
             if n_sel <= self.sel_cap:
+                self.pos_prev = pos_prev
                 return self.sel[:n_sel].clone(), min_dist, first
             self._grow(n_sel)
 
-    def violations(self, pos_new, p0, v0, feas_tol):
-        """rows outside the working set violated at pos_new -> (rows tensor, max_violation)."""
+    def violations(self, pos_new, p0, v0, feas_tol, recompute=True):
+        """rows outside the working set violated at pos_new -> (rows tensor, max_violation).
+
+        recompute (default): eta and l are recomputed from the linearisation point kept by linearize() instead of
+        streaming the stored rows back from HBM (scp_collision_violations_at); False reads the stored rows."""
         c = self.ctx
-        torch = _torch()
         while True:
-            snapshot = self.bitmap.clone()
-            c.check(c.lib.scp_collision_violations(c.h, self.N, self.K, self.D, self.h, self.q_begin, self.q_end,
-                                                   self.eta.data_ptr(), self.l.data_ptr(), pos_new.data_ptr(),
-                                                   p0.data_ptr(), v0.data_ptr(), feas_tol, self.sel.data_ptr(),
-                                                   self.sel_cap, self.bitmap.data_ptr(), c.stats.data_ptr()))
+            if recompute and self.pos_prev is not None:
+                c.check(c.lib.scp_collision_violations_at(c.h, self.N, self.K, self.D, self.R, self.q_begin, self.q_end,
+                                                          self.pos_prev.data_ptr(), pos_new.data_ptr(), feas_tol,
+                                                          self.sel.data_ptr(), self.sel_cap, self.bitmap.data_ptr(),
+                                                          c.stats.data_ptr()))
+            else:
+                c.check(c.lib.scp_collision_violations(c.h, self.N, self.K, self.D, self.h, self.q_begin, self.q_end,
+                                                       self.eta.data_ptr(), self.l.data_ptr(), pos_new.data_ptr(),
+                                                       p0.data_ptr(), v0.data_ptr(), feas_tol, self.sel.data_ptr(),
+                                                       self.sel_cap, self.bitmap.data_ptr(), c.stats.data_ptr()))
             _, _, n_sel, max_v = c.read_stats()
             self.last_violations_ms = c.last_pair_ms() if self.nq > 0 else 0.0
             if n_sel <= self.sel_cap:
                 return self.sel[:n_sel].clone(), max_v
-            self.bitmap.copy_(snapshot)
+            # the list was too short: the library merged nothing into the working-set bitmap (n_selected > capacity), so
+            # the pass is simply repeated with a longer list
             self._grow(n_sel)
 
     def gather(self, rows):

@@ -145,11 +145,21 @@ int scp_check_avoidance(scp_ctx* ctx, int N, int K, int D, double R, int64_t q_b
 /* ---- constraint generation for the joint QP (a6): full pass over the linearised rows ------------------
  * For every local row not yet marked in sel_bitmap: if (A_col x)_r < l_r - feas_tol, mark it and append its
  * global id to new_rows.  (A_col x)_r = eta_r . ((pos_i - c_i) - (pos_j - c_j))[k], c = p0 + k h v0,
- * pos = kinematics(x).  stats->n_selected = rows appended, stats->max_violation. */
+ * pos = kinematics(x).  stats->n_selected = rows found, stats->max_violation.  If n_selected exceeds new_cap NOTHING is
+ * merged into sel_bitmap and new_rows is left untouched: repeat the call with a longer list. */
 int scp_collision_violations(scp_ctx* ctx, int N, int K, int D, double h, int64_t q_begin, int64_t q_end,
                              const double* eta, const double* l_col, const double* pos, const double* p0,
                              const double* v0, double feas_tol, int64_t* new_rows, int64_t new_cap,
                              uint32_t* sel_bitmap, scp_pair_stats* stats);
+
+/* The same pass without reading the stored rows back: eta_r and R - dist_r are recomputed from the linearisation
+ * point pos_prev (the arithmetic of scp_linearize_pairs) and
+ *   l_r - (A_col x)_r = (R - dist_r) - eta_r . ((pos_new - pos_prev)_i - (pos_new - pos_prev)_j)[k]
+ * (the free motion c cancels), so the pass streams nothing from HBM (the stored rows cost 8 (D + 1) bytes per row to
+ * read: 630 MB at 1024 x 50).  Differs from scp_collision_violations by rounding only (one fused sum instead of two). */
+int scp_collision_violations_at(scp_ctx* ctx, int N, int K, int D, double R, int64_t q_begin, int64_t q_end,
+                                const double* pos_prev, const double* pos_new, double feas_tol, int64_t* new_rows,
+                                int64_t new_cap, uint32_t* sel_bitmap, scp_pair_stats* stats);
 
 /* Gather the compact rows `rows` (global ids, all inside [q_begin,q_end) x K) out of (eta, l_col):
  * w_eta[n][D] (AoS) and w_l[n]. */

@@ -162,8 +162,11 @@ def test_degenerate_pair(ctx):
     np.testing.assert_allclose(pp.l_rows().cpu().numpy(), l_o, rtol=0, atol=1e-15)
 
 
+@pytest.mark.parametrize("recompute", [True, False])
 @pytest.mark.parametrize("N,K,D,seed", [(9, 12, 2, 21), (40, 50, 2, 22), (30, 25, 3, 23), (280, 6, 2, 24), (270, 3, 3, 25)])
-def test_collision_violations_pass(ctx, N, K, D, seed):
+def test_collision_violations_pass(ctx, N, K, D, seed, recompute):
+    """Both forms of the pass: recomputing eta / l from the linearisation point (scp_collision_violations_at, the
+    default: nothing streamed from HBM) and reading the stored rows (scp_collision_violations)."""
     from path_planning import _hip
 
     prob, acc = synth(N, K, D, seed)
@@ -178,12 +181,19 @@ def test_collision_violations_pass(ctx, N, K, D, seed):
     ax = so.collision_apply(prob, eta_o, x.ravel())
     viol = l_o - ax
     want = sorted(r for r in np.nonzero(viol > 1e-6)[0].tolist() if r not in W)
-    new_rows, max_v = pp.violations(ctx.tensor(pos_new), p0, v0, 1e-6)
+    new_rows, max_v = pp.violations(ctx.tensor(pos_new), p0, v0, 1e-6, recompute=recompute)
     assert sorted(new_rows.cpu().numpy().tolist()) == want
     assert abs(max_v - viol.max()) < 1e-11
     # second call: everything already marked
-    again, _ = pp.violations(ctx.tensor(pos_new), p0, v0, 1e-6)
+    again, _ = pp.violations(ctx.tensor(pos_new), p0, v0, 1e-6, recompute=recompute)
     assert again.numel() == 0
+    # a list that is too short: nothing is merged, the pass is repeated with a longer list and finds the same rows
+    if len(want) > 3:
+        tiny = _hip.PairPass(ctx, N, K, D, prob.R, prob.h, sel_cap=max(len(W), 1))
+        rows_t, _, _ = tiny.linearize(ctx.tensor(pos), p0, v0, 0.2)
+        tiny.sel_cap = 2
+        got, _ = tiny.violations(ctx.tensor(pos_new), p0, v0, 1e-6, recompute=recompute)
+        assert sorted(got.cpu().numpy().tolist()) == want and tiny.sel_cap >= len(want)
 
 
 def test_rel_step(ctx):

@@ -452,6 +452,11 @@ struct Carver {
   }
 };
 
+size_t kkt_slot_doubles(int K) {  // Hf, HS, Minv, T + packed HS, Minv, T, each 256-byte aligned
+  auto al = [](size_t n) { return (n + 31) / 32 * 32; };
+  return al((size_t)K * K) * 3 + al((size_t)2 * K * K) + al(scp_packed_count(2 * K, K)) + 2 * al(scp_packed_count(K, K));
+}
+
 size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   const int Rf = 4 * K - 1;
   Carver c{static_cast<char*>(ws), 0};
@@ -459,9 +464,7 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.Ft = c.take<double>((size_t)Rf * K);
   d.S0 = c.take<double>((size_t)K * K);
   d.S0t = c.take<double>((size_t)K * K);
-  d.HS = c.take<double>((size_t)2 * K * K);
-  d.Hf = c.take<double>((size_t)K * K);
-  d.Minv = c.take<double>((size_t)K * K);
+  d.HS = d.Hf = d.Minv = nullptr;  // rho-dependent blocks live in the cache slots (carve_kkt_slots), set by build_kkt
   d.aug = c.take<double>((size_t)2 * K * K);
   d.wrow = c.take<double>((size_t)Rf);
   d.G0 = c.take<double>((size_t)K * K);
@@ -469,10 +472,8 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.pFt = c.take<double>(scp_packed_count(K, Rf));
   d.pS0 = c.take<double>(scp_packed_count(K, K));
   d.pS0t = c.take<double>(scp_packed_count(K, K));
-  d.pHS = c.take<double>(scp_packed_count(2 * K, K));
-  d.pMinv = c.take<double>(scp_packed_count(K, K));
-  d.T = c.take<double>((size_t)K * K);
-  d.pT = c.take<double>(scp_packed_count(K, K));
+  d.pHS = d.pMinv = d.T = d.pT = nullptr;
+  d.kkt_pool = c.take<double>((size_t)SCP_KKT_SLOTS * kkt_slot_doubles(K));
   const size_t nf = (size_t)Rf * C, nx = (size_t)K * C;
   d.lf = c.take<double>(nf);
   d.uf = c.take<double>(nf);
@@ -569,9 +570,29 @@ int dot_partial(scp_qp* qp, const double* a, const double* b, double* part) {
 }
 
 int build_kkt(scp_qp* qp) {
-  const QpDev& d = qp->d;
+  QpDev& d = qp->d;
   const int K = qp->K;
   hipStream_t s = qp->ctx->stream;
+  if (!qp->consts_packed) {
+    QP_CHECK(scp_qp_pack_operands(qp, true));
+    qp->consts_packed = true;
+  }
+  // cache lookup: the blocks of this (rho, sigma) may still be resident
+  scp_qp::KktSlot* slot = nullptr;
+  for (auto& k : qp->kkt)
+    if (k.used && k.rho == qp->rho && k.sigma == qp->st.sigma) slot = &k;
+  const bool hit = slot != nullptr;
+  if (!hit) {
+    slot = &qp->kkt[0];
+    for (auto& k : qp->kkt)
+      if (k.used < slot->used) slot = &k;  // empty (0) or least recently used
+  }
+  slot->used = ++qp->kkt_clock;
+  d.Hf = slot->Hf; d.HS = slot->HS; d.Minv = slot->Minv; d.T = slot->T;
+  d.pHS = slot->pHS; d.pMinv = slot->pMinv; d.pT = slot->pT;
+  if (hit) return SCP_OK;
+  slot->rho = qp->rho;
+  slot->sigma = qp->st.sigma;
   hipLaunchKernelGGL(build_hf_kernel, grid1((int64_t)K * K), dim3(256), 0, s, K, qp->rho, qp->st.sigma, d.G0, d.S0, d.Hf,
                      d.HS, d.aug);
   QP_LAUNCHED(qp);
@@ -586,7 +607,7 @@ int build_kkt(scp_qp* qp) {
   QP_LAUNCHED(qp);
   // T = S0 H_f^{-1}: the persistent kernel forms S0 p = T r on spare matrix-core waves next to p = H_f^{-1} r
   QP_CHECK(scp_launch_gemm(qp->ctx, 1, K, K, K, 1.0, d.S0, d.Minv, 0.0, d.T));
-  return scp_qp_pack_operands(qp);
+  return scp_qp_pack_operands(qp, false);
 }
 
 int admm_iteration(scp_qp* qp, int* cg_count) {
@@ -774,6 +795,25 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
   qp->qx_sel = 0;
   qp->rho = s->rho;
   carve(qp->d, workspace, K, qp->C, row_capacity, D);
+  {
+    auto al = [](size_t n) { return (n + 31) / 32 * 32; };
+    double* base = qp->d.kkt_pool;
+    for (auto& k : qp->kkt) {
+      double* q = base;
+      k.rho = k.sigma = 0.0;
+      k.used = 0;
+      k.Hf = q; q += al((size_t)K * K);
+      k.Minv = q; q += al((size_t)K * K);
+      k.T = q; q += al((size_t)K * K);
+      k.HS = q; q += al((size_t)2 * K * K);
+      k.pHS = q; q += al(scp_packed_count(2 * K, K));
+      k.pMinv = q; q += al(scp_packed_count(K, K));
+      k.pT = q;
+      base += kkt_slot_doubles(K);
+    }
+    qp->kkt_clock = 0;
+    qp->consts_packed = false;
+  }
   qp->check_seq = 0;
   qp->persist_off = false;
   qp->persist_cap_nW = -1;

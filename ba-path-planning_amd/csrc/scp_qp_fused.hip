@@ -1426,18 +1426,22 @@ __global__ __launch_bounds__(256) void pack_operands_kernel(PackArgs a) {
 }
 }  // namespace
 
-int scp_qp_pack_operands(scp_qp* qp) {
+int scp_qp_pack_operands(scp_qp* qp, bool constants) {
   const QpDev& d = qp->d;
   const int K = qp->K, Rf = qp->Rf;
   PackArgs a;
-  a.m[0] = {d.F, d.pF, Rf, K};
-  a.m[1] = {d.Ft, d.pFt, K, Rf};
-  a.m[2] = {d.S0, d.pS0, K, K};
-  a.m[3] = {d.S0t, d.pS0t, K, K};
-  a.m[4] = {d.HS, d.pHS, 2 * K, K};
-  a.m[5] = {d.Minv, d.pMinv, K, K};
-  a.m[6] = {d.T, d.pT, K, K};
-  hipLaunchKernelGGL(pack_operands_kernel, dim3(16, 7), dim3(256), 0, qp->ctx->stream, a);
+  int n = 0;
+  if (constants) {
+    a.m[n++] = {d.F, d.pF, Rf, K};
+    a.m[n++] = {d.Ft, d.pFt, K, Rf};
+    a.m[n++] = {d.S0, d.pS0, K, K};
+    a.m[n++] = {d.S0t, d.pS0t, K, K};
+  } else {
+    a.m[n++] = {d.HS, d.pHS, 2 * K, K};
+    a.m[n++] = {d.Minv, d.pMinv, K, K};
+    a.m[n++] = {d.T, d.pT, K, K};
+  }
+  hipLaunchKernelGGL(pack_operands_kernel, dim3(16, n), dim3(256), 0, qp->ctx->stream, a);
   FUSED_LAUNCHED(qp);
   return SCP_OK;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include "scp_common.h"
 
+constexpr int SCP_KKT_SLOTS = 6;  // cached rho values per solver object
 constexpr int NPART = 128;  // partial sums of a dot product (fixed -> deterministic summation order)
 
 enum Slot {  // device scalar slots (doubles)
@@ -45,6 +46,7 @@ struct QpDev {
   double* gval2;  // [2 cap]   row vectors of a termination check: yc ...
   double* gval3;  // [2 cap]   ... and delta-yc (gval keeps the pipeline's values across a check)
   int *pos_i, *pos_j;  // [cap] entry positions of row n
+  double* kkt_pool;  // SCP_KKT_SLOTS cache slots of the rho-dependent blocks
   unsigned long long* sync_words;  // SCP_SYNC_WORDS: give-up word of the persistent kernel, scratch
   unsigned long long* cells;       // [K][N][D][2] tagged granules: S0 p cells published by the persistent kernel
   unsigned long long* gpart;       // SCP_GPART_WORDS tagged granules: line-search partials, two alternating buffers
@@ -65,6 +67,16 @@ struct scp_qp {
   int qx_sel;      // which half of HQ holds S0 x (the single-step pipeline ping-pongs: 0 -> rows [K, 2K), 1 -> [0, K))
   double rho;
   QpDev d;
+  // rho-dependent blocks (H_f, [H_f; S0], H_f^{-1}, T and their packed forms) are cached per rho: adaptive rho is snapped
+  // to a geometric grid and every solve starts from settings.rho, so the same few values recur from QP to QP and the
+  // 48 us single-workgroup inverse is paid once per value.  d.Hf / HS / Minv / T / pHS / pMinv / pT point into the active slot.
+  struct KktSlot {
+    double rho, sigma;
+    unsigned long long used;  // LRU stamp, 0 = empty
+    double *Hf, *HS, *Minv, *T, *pHS, *pMinv, *pT;
+  } kkt[SCP_KKT_SLOTS];
+  unsigned long long kkt_clock;
+  bool consts_packed;  // F, F^T, S0, S0^T are packed once
   double* h_scal;  // pinned, SL_COUNT + SCP_RESID_CAP doubles + the completion flag of a fused check
   double* h_scal_dev;  // the same memory as the device sees it: the check kernels write their partials straight to it
   unsigned long long check_seq;  // value the flag takes when the current check has finished
@@ -102,7 +114,7 @@ bool scp_qp_persist_eligible(const scp_qp* qp);
 constexpr int SCP_PERSIST_GAVE_UP = 2;  // exit code of the persistent kernel: a spin timed out, nothing was written back
 int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done);
 // (re)pack F, Ft, S0, S0t, HS, Minv into the MFMA operand order; called at the end of build_kkt
-int scp_qp_pack_operands(scp_qp* qp);
+int scp_qp_pack_operands(scp_qp* qp, bool constants);  // constants: F, F^T, S0, S0^T; else the active slot's HS, Minv, T
 static inline size_t scp_packed_count(int R, int M) { return (size_t)((R + 15) / 16) * ((M + 3) / 4) * 64; }
 // Termination-check quantities of the single-step pipeline in 3 launches (row values, column blocks, rows):
 // fills qp->h_scal[SL_RP .. SL_SUPP] like residuals() in scp_qp.hip and leaves S0 x and F x in their slabs.  Synchronises.

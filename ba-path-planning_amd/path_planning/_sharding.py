@@ -56,30 +56,37 @@ class Shard:
         return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
 
     def allgather_rows(self, rows, w_eta, w_l):
-        """Concatenate every rank's compact rows (ids (n,), eta (n, D), l (n,)) in rank order."""
+        """Concatenate every rank's compact rows (ids (n,), eta (n, D), l (n,)) in rank order.
+
+        Two collectives of fixed, padded shape (ids as int64 in their own message -- never reinterpreted as floating
+        point -- and [eta | l] as float64) plus one gather of the counts; the padding is cut on the device, the only
+        host read is the list of counts."""
         if self.world == 1:
             return rows, w_eta, w_l
         if self._host_staged(rows):
             dev = rows.device
             r, e, l = self.allgather_rows(rows.cpu(), w_eta.cpu(), w_l.cpu())
             return r.to(dev), e.to(dev), l.to(dev)
-        n = torch.tensor([rows.numel()], dtype=torch.int64, device=rows.device)
-        counts = [torch.zeros_like(n) for _ in range(self.world)]
-        dist.all_gather(counts, n, group=self.group)
-        counts = [int(c.item()) for c in counts]
-        width = max(max(counts), 1)
+        k = int(rows.numel())
         D = w_eta.shape[1] if w_eta.dim() == 2 else 1
-        # one padded message per rank: [row id as float64 bits | eta (D) | l]  -> a single collective
-        msg = torch.zeros(width, D + 2, dtype=torch.float64, device=rows.device)
-        k = rows.numel()
+        n = torch.tensor([k], dtype=torch.int64, device=rows.device)
+        counts_t = torch.empty(self.world, dtype=torch.int64, device=rows.device)
+        dist.all_gather_into_tensor(counts_t, n, group=self.group)
+        counts = counts_t.tolist()  # one host read: the shapes of the result depend on it
+        width = max(max(counts), 1)
+        ids = torch.zeros(width, dtype=torch.int64, device=rows.device)
+        vals = torch.zeros(width, D + 1, dtype=torch.float64, device=rows.device)
         if k:
-            msg[:k, 0] = rows.view(torch.float64) if rows.dtype == torch.int64 else rows.to(torch.int64).view(torch.float64)
-            msg[:k, 1 : D + 1] = w_eta.reshape(k, D)
-            msg[:k, D + 1] = w_l
-        parts = [torch.empty_like(msg) for _ in range(self.world)]
-        dist.all_gather(parts, msg, group=self.group)
-        allmsg = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
-        return allmsg[:, 0].contiguous().view(torch.int64), allmsg[:, 1 : D + 1].contiguous(), allmsg[:, D + 1].contiguous()
+            ids[:k] = rows.to(torch.int64)
+            vals[:k, :D] = w_eta.reshape(k, D)
+            vals[:k, D] = w_l
+        all_ids = torch.empty(self.world * width, dtype=torch.int64, device=rows.device)
+        all_vals = torch.empty(self.world * width, D + 1, dtype=torch.float64, device=rows.device)
+        dist.all_gather_into_tensor(all_ids, ids, group=self.group)
+        dist.all_gather_into_tensor(all_vals, vals, group=self.group)
+        keep = torch.cat([torch.arange(r * width, r * width + c, device=rows.device) for r, c in enumerate(counts)])
+        all_ids, all_vals = all_ids[keep], all_vals[keep]
+        return all_ids.contiguous(), all_vals[:, :D].contiguous(), all_vals[:, D].contiguous()
 
     def broadcast(self, tensor, src=0):
         if self.world > 1:

@@ -24,6 +24,8 @@ def build_parser():
     p.add_argument("--dim", type=int, choices=[2, 3], default=2)
     p.add_argument("--seed", type=int, default=None)
     p.add_argument("--max-iterations", type=int, default=15)
+    p.add_argument("--polish", action="store_true",
+                   help="one more joint QP at 1e-8 after the SCP loop: the result meets every constraint to ~1e-6")
     p.add_argument("--no-plots", action="store_true")
     p.add_argument("--save-prefix", default=None, help="write <prefix>_2d.pdf and <prefix>_snapshots.pdf")
     return p
@@ -63,6 +65,7 @@ def main(argv=None):
             min_distance=min_distance,
             space_dims=space_dims,
             dim=args.dim,
+            polish=args.polish,
         )
         print(f"Successfully generated positions for {n_vehicles} vehicles")
         solver.set_initial_states(np.asarray(initial_positions))

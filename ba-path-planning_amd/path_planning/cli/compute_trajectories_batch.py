@@ -79,6 +79,7 @@ def run_single_trial(N, cfg, rng=None, seed=None, device=None, scenario=None, sa
                 dim=cfg.get("dim", 2),
                 device=device,
                 verbose=cfg.get("verbose", False),
+                polish=cfg.get("polish", False),
             )
             if pool is not None:
                 pool[key] = solver
@@ -180,6 +181,8 @@ def build_parser():
     p.add_argument("--max-iterations", type=int, default=None)
     p.add_argument("--save-trajectories", action="store_true",
                    help="write <results-dir>/trajectory_N<N>_t<trial>.npz (positions, velocities, accelerations) per run")
+    p.add_argument("--polish", action="store_true",
+                   help="one more joint QP at 1e-8 after the SCP loop: the result meets every constraint to ~1e-6")
     p.add_argument("--fresh-solvers", action="store_true",
                    help="build a new solver object for every trial like the reference (:32-38) instead of reusing one per worker")
     p.add_argument("--validate", action="store_true", help="add the minimum pair distance of every result to its record")
@@ -198,6 +201,7 @@ def main(argv=None):
         if val is not None:
             cfg[key] = val
     cfg["validate"] = bool(args.validate)
+    cfg["polish"] = bool(args.polish)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -12,7 +12,7 @@ Differences to the reference that a caller can observe (INTEGRATION.md has the f
   * ``_add_collision_constraints`` returns the compact form (eta, l) of the constraint rows instead of a
     2.6e9-non-zero CSC matrix; ``C_jerk/C_acc/C_vel/C_pos`` are not materialised (they stay None);
   * new keyword-only arguments: ``dim`` (2 or 3), ``device``, ``qp_settings``, ``working_set_margin``,
-    ``feasibility_tol``, ``max_rounds``, ``refresh_feasibility``, ``qp_row_capacity``, ``verbose``,
+    ``feasibility_tol``, ``max_rounds``, ``refresh_feasibility``, ``polish``/``polish_eps``, ``qp_row_capacity``, ``verbose``,
     ``rank``/``world_size``/``group`` (agent-sharded multi-GPU).
 """
 from __future__ import annotations
@@ -41,6 +41,8 @@ class SCP:
         feasibility_tol=1e-6,
         max_rounds=20,
         refresh_feasibility=False,
+        polish=False,
+        polish_eps=1e-8,
         qp_row_capacity=None,
         verbose=True,
         rank=0,
@@ -87,6 +89,8 @@ class SCP:
         self.feasibility_tol = float(feasibility_tol)
         self.max_rounds = int(max_rounds)
         self.refresh_feasibility = bool(refresh_feasibility)
+        self.polish = bool(polish)
+        self.polish_eps = float(polish_eps)
         self._qp_row_capacity = qp_row_capacity  # initial working-set capacity (grows on demand)
         self._qp_overrides = dict(qp_settings or {})
         self.shard = Shard(self.N, rank, world_size, group)
@@ -237,6 +241,16 @@ class SCP:
                 is_feasible = self._fast_check_avoidance_constraints(pos_now)
                 self.verbose = verbose
 
+        if self.polish:
+            # opt-in (not in the reference): one more joint QP, linearised at the final trajectories and solved to
+            # polish_eps instead of OSQP's 1e-3.  Every linearised row then holds to ~polish_eps, and a satisfied row
+            # eta.(p_i - p_j) >= R implies ||p_i - p_j|| >= R, so the result passes the reference's own R - 0.01 check
+            # (scp.py:610) and meets the fixed rows to the same accuracy; the reference's loop stops at OSQP's tolerance,
+            # which leaves millimetres of violation in a converged result.
+            t_p = time.perf_counter()
+            acc = self._solve_with_avoidance_constraints(acc, eps=self.polish_eps)
+            self.last_info["polish"] = dict(self._last_qp_info, time_sec=time.perf_counter() - t_p)
+
         positions, velocities = self._kinematics(acc)
         self.trajectories = {
             "positions": positions.cpu().numpy(),  # Shape (N, K, D)
@@ -337,8 +351,9 @@ class SCP:
     # ------------------------------------------------------------------------------------------------
     # a6: joint QP with collision rows (scp.py:399-451)
     # ------------------------------------------------------------------------------------------------
-    def _solve_with_avoidance_constraints(self, accelerations_flat):
+    def _solve_with_avoidance_constraints(self, accelerations_flat, eps=None):
         """Solve with collision avoidance constraints.  Takes / returns a device tensor (N, K, D).
+        eps: termination tolerances of this one QP (the polish step), None = the solver's settings.
 
         The joint QP over ALL collision rows is solved by exact constraint generation: ADMM runs on the fixed rows
         and a working set (rows with dist - R < working_set_margin at the linearisation point); a full pairwise
@@ -348,6 +363,10 @@ class SCP:
         pp = self._ensure_pairs()
         qp = self._ensure_qp()
         max_iter = int(self._qp_overrides.get("max_iter", 10000))  # scp.py:442
+        eps_saved = (qp.settings.eps_abs, qp.settings.eps_rel)
+        if eps is not None:
+            qp.update_settings(eps_abs=float(eps), eps_rel=float(eps))
+            max_iter = max(max_iter, 40000)  # three more digits take a few times OSQP's budget
 
         prev_pos, _ = self._kinematics(acc, want_vel=False)
         rows, _, _ = pp.linearize(prev_pos, p0, v0, self.working_set_margin)
@@ -397,6 +416,8 @@ class SCP:
                 qp = self._grow_qp(qp.n_rows + int(new_rows.numel()), keep_state=True)
                 qp.add_rows(new_rows, n_eta, n_l)
 
+        if eps is not None:
+            self._qp.update_settings(eps_abs=eps_saved[0], eps_rel=eps_saved[1])
         self._last_qp_info = dict(info, **total, rounds=len(added), added=added, unresolved_rows=added[-1],
                                   max_violation=max_v)
         if info["status_val"] not in (1, 2):  # scp.py:446-447

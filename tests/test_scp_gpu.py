@@ -439,3 +439,29 @@ def test_against_reference_proxy(n, seed):
     assert abs(s.last_info["n_iterations"] - ref["iterations"]) <= 1
     np.testing.assert_allclose(traj["positions"], ref["positions"], rtol=0, atol=PROXY_TOL)
     assert so.min_pair_distance(prob, traj["positions"]) >= 0.8 - 0.01  # scp.py:610
+
+
+@pytest.mark.parametrize("kind,n,seed", [("ref", 10, 7), ("ref", 17, 331), ("grid", 64, 64000), ("grid3d", 27, 17)])
+def test_polish_meets_every_constraint(kind, n, seed):
+    """polish=True: one more joint QP at 1e-8 after the loop.  The returned point then satisfies every constraint of the
+    reference QP to 1e-6 (fixed rows, final state) and keeps all pairs at >= R - 1e-6 -- hence passes the reference's own
+    R - 0.01 check (scp.py:610), which a result at OSQP's 1e-3 can miss by millimetres."""
+    from path_planning.scenarios.position_generator import generate_grid_swap
+
+    dim = 3 if kind == "grid3d" else 2
+    if kind == "ref":
+        p0, pf = ref_scenario(n, seed)
+        space = [0, 0, 20, 20]
+    else:
+        p0, pf, space = generate_grid_swap(n, seed=seed, dim=dim)
+    s, traj = solve_gpu(n, 10.0, 0.2, 0.8, space, p0, pf, dim=dim, polish=True)
+    assert s.last_info["polish"]["status_val"] in (1, 2) and s.last_info["polish"]["unresolved_rows"] == 0
+    check_solution_properties(s, traj, tol=1e-6)
+    rep = s.validate_solution()
+    assert rep["collision_free"] and rep["min_pair_distance"] >= 0.8 - 1e-6, rep
+    for key in ("acc_violation", "jerk_violation", "vel_violation", "pos_violation", "final_position_error",
+                "final_velocity_error"):
+        assert rep[key] < 1e-6, (key, rep[key])
+    # without it the same solve stops at OSQP's tolerance
+    s0, t0 = solve_gpu(n, 10.0, 0.2, 0.8, space, p0, pf, dim=dim)
+    assert "polish" not in s0.last_info and np.abs(t0["positions"] - traj["positions"]).max() < 5e-2

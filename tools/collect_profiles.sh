@@ -1,0 +1,53 @@
+#!/bin/bash
+# Developer tool: everything that backs the numbers in DESIGN.md / profiles/README.md, in one run on the GPU box.
+#   gpurun -- 'bash tools/collect_profiles.sh r02'      -> gpurun_out/<tag>/...   (copy the summaries into profiles/)
+# rocprofv3 runs from /tmp (its scratch files), counters in their own passes (--kernel-trace only next to --pmc).
+set -u
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp PYTHONPATH=$R/ba-path-planning_amd
+cd /tmp
+
+echo "== bench (with the CPU baseline)"
+timeout -k 10 400 python3 $R/bench.py --steps 20 --warmup 2 > $OUT/bench_n1024.json 2> $OUT/bench_n1024.err
+tail -c 600 $OUT/bench_n1024.json; echo
+
+echo "== kernel stats of the bench"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -- python3 $R/bench.py --steps 10 --no-cpu-baseline > $OUT/prof_bench.log 2>&1
+cp $(find $OUT/prof_bench -name "*kernel_stats.csv" | head -1) $OUT/bench_n1024_kernel_stats.csv 2>/dev/null
+
+echo "== HBM counters of the pairwise passes (separate passes)"
+for C in WRITE_SIZE FETCH_SIZE; do
+  timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 $R/tools/pair_bench.py --reps 3 > $OUT/pmc_$C.log 2>&1
+  cp $(find $OUT/pmc_$C -name "*counter_collection.csv" | head -1) $OUT/pairwise_pmc_$C.csv 2>/dev/null
+done
+timeout -k 10 200 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_TCC -- python3 $R/tools/pair_bench.py --reps 3 > $OUT/pmc_TCC.log 2>&1
+cp $(find $OUT/pmc_TCC -name "*counter_collection.csv" | head -1) $OUT/pairwise_pmc_TCC.csv 2>/dev/null
+
+echo "== matrix-core counters of the QP kernels"
+rocprofv3 -L 2>/dev/null | grep -i -o "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*" | sort -u > $OUT/mfma_counter_names.txt
+cat $OUT/mfma_counter_names.txt | tr '\n' ' '; echo
+timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_mfma.log 2>&1
+cp $(find $OUT/pmc_mfma -name "*counter_collection.csv" | head -1) $OUT/qp_pmc_mfma_raw.csv 2>/dev/null
+timeout -k 10 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_lds -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_lds.log 2>&1
+cp $(find $OUT/pmc_lds -name "*counter_collection.csv" | head -1) $OUT/qp_pmc_lds_raw.csv 2>/dev/null
+
+cd $R
+echo "== phase profile of the persistent kernel"
+timeout -k 10 200 python3 tools/phase_profile.py 1024 > $OUT/phase_profile_n1024.txt 2>&1
+head -12 $OUT/phase_profile_n1024.txt
+echo "== 4096 x 50 on one GPU, full solves, soak, batch"
+timeout -k 10 300 python3 bench.py --agents 4096 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_n4096_1gpu.json 2> $OUT/bench_n4096.err
+timeout -k 10 200 python3 tools/full_solve_timing.py 64 256 1024 4096 > $OUT/full_solve_timing.txt 2>&1
+timeout -k 10 200 python3 tools/ref_config_timing.py > $OUT/ref_config_timing.txt 2>&1
+timeout -k 10 300 python3 tools/soak.py 80 > $OUT/soak_80.txt 2>&1; tail -1 $OUT/soak_80.txt
+timeout -k 10 300 python3 tools/soak.py 80 --polish > $OUT/soak_80_polish.txt 2>&1; tail -1 $OUT/soak_80_polish.txt
+for S in 1 4; do
+  timeout -k 10 250 python3 -m path_planning.cli.compute_trajectories_batch --Ns 128 --trials 96 --scenario grid-swap --seed 1 --results-dir /tmp/b$S --streams $S 2>&1 | grep "scenarios/s"
+done > $OUT/batch128.txt 2>&1
+cat $OUT/batch128.txt
+timeout -k 10 100 python3 -m path_planning.cli.compute_trajectories --seed 3 --no-plots > $OUT/demo_k500.txt 2>&1; tail -4 $OUT/demo_k500.txt
+timeout -k 10 60 tools/bin/grid_sync_bench 2000 > $OUT/grid_sync_bench.txt 2>&1
+echo "== done"

@@ -16,6 +16,8 @@ from path_planning.solvers.scp import SCP  # noqa: E402
 
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    polish = "--polish" in sys.argv  # one tight final QP: converged results must then pass the reference's R - 0.01 check
+    floor = 0.8 - (0.01 if polish else 0.02)
     rng = np.random.default_rng(2026)
     bad = 0
     t0 = time.perf_counter()
@@ -33,7 +35,7 @@ def main():
         outs = []
         err = None
         for rep in range(2):
-            s = SCP(N, T, 0.2, 0.8, space, dim=dim, verbose=False)
+            s = SCP(N, T, 0.2, 0.8, space, dim=dim, verbose=False, polish=polish)
             s.set_initial_states(p0)
             s.set_final_states(pf)
             try:
@@ -48,7 +50,11 @@ def main():
         finite = bool(np.isfinite(outs[0]).all())
         same = bool(np.array_equal(outs[0], outs[1]))
         conv = s.last_info.get("converged")
-        ok = finite and same and (rep_["min_pair_distance"] >= 0.8 - 0.02 or not conv)
+        ok = finite and same and (rep_["min_pair_distance"] >= floor or not conv)
+        if polish and conv:
+            worst = max(rep_[k] for k in ("acc_violation", "jerk_violation", "vel_violation", "pos_violation",
+                                         "final_position_error", "final_velocity_error"))
+            ok = ok and worst < 1e-5
         bad += 0 if ok else 1
         print(f"case {case}: {kind} N={N} D={dim} T={T}: iterations={s.last_info['n_iterations']} converged={conv} "
               f"collision_free={rep_['collision_free']} min_dist={rep_['min_pair_distance']:.4f} finite={finite} "

@@ -10,6 +10,8 @@
 // An ADMM step with n PCG steps is 4n + 3 launches, 7 at the default n = 1 (15n + ... on the generic path of scp_qp.hip, which stays as the fallback
 // for K > 128 and as the use_mfma = 0/2 reference); the arithmetic is the same, statement by statement.
 #include "scp_qp_device.h"
+#include <sched.h>
+
 #include <chrono>
 #include <cstdlib>
 
@@ -1751,6 +1753,7 @@ int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
 #if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
 #endif
+      if ((spins & 0x3F) == 0x3F) sched_yield();  // many solver threads may share the host's cores (batch CLI)
       if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
     }
     if (*flag != seq) SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // a fault surfaces here

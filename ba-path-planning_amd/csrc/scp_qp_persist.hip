@@ -25,6 +25,8 @@
 // state back, and the host repeats the iterations on the three-launch pipeline.
 #include "scp_qp_device.h"
 
+#include <sched.h>
+
 #include <chrono>
 
 namespace {
@@ -819,6 +821,7 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
 #if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
 #endif
+      if ((spins & 0x3F) == 0x3F) sched_yield();  // many solver threads may share the host's cores (batch CLI)
       if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) break;
     }
     if (*flag != a.seq) SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // a fault surfaces here

@@ -39,6 +39,51 @@ class QpSettings(C.Structure):
     ]
 
 
+MAX_ROUNDS_RECORDED = 24
+
+
+class SolveOptions(C.Structure):
+    """struct scp_solve_options"""
+
+    _fields_ = [
+        ("max_iterations", C.c_int32), ("max_rounds", C.c_int32), ("max_iter0", C.c_int32), ("max_iter", C.c_int32),
+        ("refresh_feasibility", C.c_int32), ("polish", C.c_int32), ("working_set_margin", C.c_double),
+        ("feasibility_tol", C.c_double), ("polish_eps", C.c_double), ("convergence_tolerance", C.c_double),
+    ]
+
+
+class QpRecord(C.Structure):
+    """struct scp_qp_record"""
+
+    _fields_ = [
+        ("status_val", C.c_int32), ("iter", C.c_int32), ("rho_updates", C.c_int32), ("cg_iters_total", C.c_int32),
+        ("rounds", C.c_int32), ("reserved", C.c_int32), ("working_rows", C.c_int64), ("unresolved_rows", C.c_int64),
+        ("added", C.c_int64 * MAX_ROUNDS_RECORDED), ("r_prim", C.c_double), ("r_dual", C.c_double), ("rho", C.c_double),
+        ("solve_ms", C.c_double), ("max_violation", C.c_double), ("rel_step", C.c_double), ("time_sec", C.c_double),
+    ]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k in ("status_val", "iter", "rho_updates", "cg_iters_total", "working_rows", "r_prim",
+                                            "r_dual", "rho", "solve_ms")}
+        d["status"] = STATUS_TEXT.get(self.status_val, str(self.status_val))
+        d["rounds"] = int(self.rounds)
+        d["added"] = [int(self.added[i]) for i in range(min(self.rounds, MAX_ROUNDS_RECORDED))]
+        d["unresolved_rows"] = int(self.unresolved_rows)
+        d["max_violation"] = float(self.max_violation)
+        return d
+
+
+class SolveResult(C.Structure):
+    """struct scp_solve_result"""
+
+    _fields_ = [
+        ("n_iterations", C.c_int32), ("converged", C.c_int32), ("initially_feasible", C.c_int32),
+        ("feasible_at_exit", C.c_int32), ("polished", C.c_int32), ("qp0_status", C.c_int32), ("n_records", C.c_int32),
+        ("first_violation_k", C.c_int32), ("first_violation_i", C.c_int32), ("first_violation_j", C.c_int32),
+        ("first_violation", C.c_uint64), ("first_violation_distance", C.c_double), ("time_sec", C.c_double),
+    ]
+
+
 class QpInfo(C.Structure):
     """struct scp_qp_info"""
 
@@ -62,6 +107,7 @@ EXPORTS = [
     "scp_qp_workspace_bytes", "scp_qp_create", "scp_qp_destroy", "scp_qp_update_settings", "scp_qp_set_problem",
     "scp_qp_reset", "scp_qp_add_rows", "scp_qp_solve", "scp_qp_clone_state", "scp_qp_get_solution",
     "scp_qp_get_duals", "scp_gemm_f64", "scp_qp_peek",
+    "scp_solve_default_options", "scp_solver_create", "scp_solver_destroy", "scp_solver_update_settings", "scp_solver_solve",
 ]
 
 
@@ -118,6 +164,14 @@ def load_library():
     lib.scp_qp_get_duals.argtypes = [vp, vp, vp]
     lib.scp_gemm_f64.argtypes = [vp, i32, i32, i32, i32, f64, vp, vp, f64, vp]
     lib.scp_qp_peek.argtypes = [vp, C.c_char_p, vp, i64, C.POINTER(i64)]
+    lib.scp_solve_default_options.argtypes = [C.POINTER(SolveOptions)]
+    lib.scp_solve_default_options.restype = None
+    lib.scp_solver_create.argtypes = [vp, i32, i32, i32, f64, f64, C.POINTER(QpSettings), i64, C.POINTER(vp)]
+    lib.scp_solver_destroy.argtypes = [vp]
+    lib.scp_solver_destroy.restype = None
+    lib.scp_solver_update_settings.argtypes = [vp, C.POINTER(QpSettings)]
+    lib.scp_solver_solve.argtypes = [vp, pd, pd, vp, vp, vp, vp, C.POINTER(SolveOptions), vp, vp, vp, C.POINTER(SolveResult),
+                                     C.POINTER(QpRecord), i32]
     _LIB, _LIB_PATH = lib, path
     return lib
 
@@ -407,3 +461,46 @@ class QP:
         yc = self.ctx.empty(max(self.n_rows, 1))
         self.ctx.check(self.ctx.lib.scp_qp_get_duals(self.h_qp, yf.data_ptr(), yc.data_ptr()))
         return yf, yc[: self.n_rows]
+
+
+class NativeSolver:
+    """scp_solver: the whole SCP loop behind one call (scp_solver_solve)."""
+
+    def __init__(self, ctx: Context, N, K, D, h, R, settings: QpSettings, row_capacity=None):
+        self.ctx, self.N, self.K, self.D = ctx, N, K, D
+        self.settings = settings
+        hnd = C.c_void_p()
+        ctx.check(ctx.lib.scp_solver_create(ctx.h, N, K, D, h, R, C.byref(settings), int(row_capacity or 0), C.byref(hnd)))
+        self.h_solver = hnd
+
+    def close(self):
+        if getattr(self, "h_solver", None) and getattr(self.ctx, "h", None):
+            self.ctx.lib.scp_solver_destroy(self.h_solver)
+        self.h_solver = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def default_options(self, **kw) -> SolveOptions:
+        o = SolveOptions()
+        self.ctx.lib.scp_solve_default_options(C.byref(o))
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
+
+    def solve(self, limits, space, p0, v0, pf, vf, options: SolveOptions):
+        """-> (acc, pos, vel device tensors (N, K, D), SolveResult, [QpRecord ...])"""
+        c = self.ctx
+        acc, pos, vel = c.empty(self.N, self.K, self.D), c.empty(self.N, self.K, self.D), c.empty(self.N, self.K, self.D)
+        la, lp = _harr(limits)
+        sa, sp = _harr(space)
+        res = SolveResult()
+        cap = int(options.max_iterations) + 2
+        recs = (QpRecord * cap)()
+        c.check(c.lib.scp_solver_solve(self.h_solver, lp, sp, p0.data_ptr(), v0.data_ptr(), pf.data_ptr(), vf.data_ptr(),
+                                       C.byref(options), acc.data_ptr(), pos.data_ptr(), vel.data_ptr(), C.byref(res), recs,
+                                       cap))
+        return acc, pos, vel, res, [recs[i] for i in range(res.n_records)]

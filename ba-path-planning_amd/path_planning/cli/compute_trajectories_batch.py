@@ -194,6 +194,10 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args([] if argv is None else argv)
+    if args.streams > 1:
+        # HIP maps streams onto 4 hardware queues by default and kernels of streams that share a queue run one after the
+        # other -- a persistent QP kernel holds its queue for a millisecond.  Effective only before the runtime starts.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(max(4, args.streams), 24)))
     cfg = CONFIG.copy()
     for key, val in (("Ns", args.Ns), ("trials_per_N", args.trials), ("scenario", args.scenario), ("dim", args.dim),
                      ("rng_seed", args.seed), ("results_dir", args.results_dir),

@@ -12,7 +12,7 @@ Differences to the reference that a caller can observe (INTEGRATION.md has the f
   * ``_add_collision_constraints`` returns the compact form (eta, l) of the constraint rows instead of a
     2.6e9-non-zero CSC matrix; ``C_jerk/C_acc/C_vel/C_pos`` are not materialised (they stay None);
   * new keyword-only arguments: ``dim`` (2 or 3), ``device``, ``qp_settings``, ``working_set_margin``,
-    ``feasibility_tol``, ``max_rounds``, ``refresh_feasibility``, ``polish``/``polish_eps``, ``qp_row_capacity``, ``verbose``,
+    ``feasibility_tol``, ``max_rounds``, ``refresh_feasibility``, ``polish``/``polish_eps``, ``native``, ``qp_row_capacity``, ``verbose``,
     ``rank``/``world_size``/``group`` (agent-sharded multi-GPU).
 """
 from __future__ import annotations
@@ -43,6 +43,7 @@ class SCP:
         refresh_feasibility=False,
         polish=False,
         polish_eps=1e-8,
+        native=True,
         qp_row_capacity=None,
         verbose=True,
         rank=0,
@@ -91,6 +92,8 @@ class SCP:
         self.refresh_feasibility = bool(refresh_feasibility)
         self.polish = bool(polish)
         self.polish_eps = float(polish_eps)
+        self.native = bool(native)  # drive the SCP loop from C++ (scp_solver_solve) instead of from Python: same calls, same bits
+        self._native = None
         self._qp_row_capacity = qp_row_capacity  # initial working-set capacity (grows on demand)
         self._qp_overrides = dict(qp_settings or {})
         self.shard = Shard(self.N, rank, world_size, group)
@@ -208,6 +211,8 @@ class SCP:
     # ------------------------------------------------------------------------------------------------
     def generate_trajectories(self, max_iterations=15):
         """Main method to generate collision-free trajectories using SCP (scp.py:131-180)."""
+        if self.native and self.shard.world == 1:
+            return self._generate_trajectories_native(max_iterations)
         is_feasible = False
         start_time = time.time()
 
@@ -262,10 +267,71 @@ class SCP:
         self._print(f"Trajectory generation completed in {end_time - start_time:.3f} seconds")
         return self.trajectories
 
+    def _generate_trajectories_native(self, max_iterations):
+        """generate_trajectories with the loop driven by scp_solver_solve (one C call; the Python-driven loop above makes
+        the same library calls in the same order and gives bit-identical results).  The reference's stdout lines are
+        printed from the returned records, in the reference's order."""
+        start_time = time.time()
+        self._fill_bound_attributes()
+        if self._native is None:
+            known = {k for k, _ in _hip.QpSettings._fields_}
+            st = _hip.default_settings(**{k: v for k, v in self._qp_overrides.items() if k in known})
+            self._native = _hip.NativeSolver(self._ctx, self.N, self.K, self.D, self.h, self.R, st,
+                                             row_capacity=self._qp_row_capacity)
+        nat = self._native
+        p0, v0, pf, vf = self._states()
+        opts = nat.default_options(
+            max_iterations=int(max_iterations), max_rounds=self.max_rounds,
+            max_iter0=int(self._qp_overrides.get("max_iter0", self._qp_overrides.get("max_iter", 4000))),
+            max_iter=int(self._qp_overrides.get("max_iter", 10000)), refresh_feasibility=int(self.refresh_feasibility),
+            polish=int(self.polish), working_set_margin=self.working_set_margin, feasibility_tol=self.feasibility_tol,
+            polish_eps=self.polish_eps, convergence_tolerance=self.convergence_tolerance)
+        acc, pos, vel, res, recs = nat.solve(self._limits(), self._space(), p0, v0, pf, vf, opts)
+        qp0 = dict(recs[0].as_dict(), rounds=1, added=[])
+        self._last_qp_info = qp0
+        if res.qp0_status not in (1, 2):  # Solved / Solved Inaccurate (scp.py:363-365)
+            self._print("not feasible")
+            raise RuntimeError(f"OSQP failed: {qp0['status']}")
+        if not res.initially_feasible:
+            self._print(f"Avoidance constraint violation at timestep {res.first_violation_k} between vehicles "
+                        f"{res.first_violation_i} and {res.first_violation_j}: distance = {res.first_violation_distance:.3f}")
+        its = []
+        for n, r in enumerate(recs[1:1 + res.n_iterations]):
+            d = dict(r.as_dict(), rel_step=float(r.rel_step), time_sec=float(r.time_sec))
+            self._print(f"SCP Iteration {n+1}")
+            if d["status_val"] not in (1, 2):  # scp.py:446-447
+                self._print(f"Warning: OSQP status {d['status']}")
+            elif d["unresolved_rows"]:
+                self._print(f"Warning: OSQP status constraint generation stopped with {d['unresolved_rows']} violated "
+                            f"collision rows outside the working set (max violation {d['max_violation']:.3e})")
+            self._print(d["rel_step"])
+            if d["rel_step"] <= self.convergence_tolerance:
+                self._print(f"Converged after {n+1} iterations.")
+            its.append(d)
+        self.last_info = {"iterations": its, "qp0": qp0, "converged": bool(res.converged),
+                          "initially_feasible": bool(res.feasible_at_exit), "n_iterations": int(res.n_iterations)}
+        if res.polished:
+            r = recs[res.n_records - 1]
+            self.last_info["polish"] = dict(r.as_dict(), time_sec=float(r.time_sec))
+        if its:
+            self._last_qp_info = its[-1]
+        self.trajectories = {
+            "positions": pos.cpu().numpy(),  # Shape (N, K, D)
+            "velocities": vel.cpu().numpy(),
+            "accelerations": acc.cpu().numpy(),
+        }
+        self._print(f"Trajectory generation completed in {time.time() - start_time:.3f} seconds")
+        return self.trajectories
+
     # ------------------------------------------------------------------------------------------------
     # a2: fixed rows (scp.py:182-321) -- bounds only; the matrices are the shared K-column blocks
     # ------------------------------------------------------------------------------------------------
     def _precompute_constraint_matrices(self):
+        p0, v0, pf, vf = self._fill_bound_attributes()
+        self._ensure_qp().set_problem(self._limits(), self._space(), p0, v0, pf, vf)
+
+    def _fill_bound_attributes(self):
+        """l_* / u_* attributes of the reference (scp.py:189-257), bitwise equal; returns the device states."""
         N, K, D = self.N, self.K, self.D
         p0, v0, pf, vf = self._states()
         lo, hi = self._ctx.fixed_bounds(N, K, D, self.h, self._limits(), self._space(), p0, v0, pf, vf)
@@ -280,7 +346,7 @@ class SCP:
         assert self.l_jerk.shape == self.u_jerk.shape == (D * N * (K - 1),)
         assert self.l_vel.shape == self.u_vel.shape == (D * N * K,)
         assert self.l_pos.shape == self.u_pos.shape == (D * N * K,)
-        self._ensure_qp().set_problem(self._limits(), self._space(), p0, v0, pf, vf)
+        return p0, v0, pf, vf
 
     # ------------------------------------------------------------------------------------------------
     # a3: QP#0 (scp.py:323-369)

@@ -199,6 +199,63 @@ int scp_qp_get_solution(scp_qp* qp, double* x_out /*[N][K][D]*/);
 /* duals: y_fixed in the reference stacking order (N*D*(4K-1)), y_col per working row (may be NULL) */
 int scp_qp_get_duals(scp_qp* qp, double* y_fixed, double* y_col);
 
+/* ---- a1 as ONE call: SCP.generate_trajectories (scp.py:131-180) driven natively ------------------------------
+ * The SCP loop is control flow around the entry points above; path_planning/solvers/scp.py drives them from Python
+ * (about a hundred calls and half a dozen blocking reads per SCP iteration).  scp_solver_solve makes the SAME calls in
+ * the SAME order from C++: QP#0, the avoidance check evaluated once (scp.py:144), then per iteration kinematics,
+ * scp_linearize_pairs, the joint QP with exact constraint generation (scp_qp_* + scp_collision_violations_at) and the
+ * relative-step test, optionally the polish QP, and the final kinematics.  Bit-identical to the Python-driven loop.
+ * The solver object owns its device memory (hipMalloc: compact rows, bitmap, row lists, QP workspace, trajectories). */
+typedef struct scp_solver scp_solver;
+
+typedef struct scp_solve_options {
+  int32_t max_iterations;       /* 15: SCP iterations (compute_trajectories.py:75) */
+  int32_t max_rounds;           /* 20: constraint-generation rounds per joint QP */
+  int32_t max_iter0;            /* 4000: ADMM iterations of QP#0 (OSQP default, scp.py:360) */
+  int32_t max_iter;             /* 10000: ADMM iterations per joint QP (scp.py:442) */
+  int32_t refresh_feasibility;  /* 0: re-evaluate is_feasible inside the loop (the reference's TODO, scp.py:150) */
+  int32_t polish;               /* 0: one more joint QP at polish_eps after the loop */
+  double working_set_margin;    /* 0.5 m */
+  double feasibility_tol;       /* 1e-6 */
+  double polish_eps;            /* 1e-8 */
+  double convergence_tolerance; /* 1.5e-2 (scp.py:52) */
+} scp_solve_options;
+
+#define SCP_MAX_ROUNDS_RECORDED 24
+/* [host] one per QP of a solve: records[0] = QP#0, then one per SCP iteration, then the polish QP if requested */
+typedef struct scp_qp_record {
+  int32_t status_val;       /* of the last constraint-generation round */
+  int32_t iter;             /* ADMM iterations, all rounds */
+  int32_t rho_updates, cg_iters_total, rounds, reserved;
+  int64_t working_rows, unresolved_rows;
+  int64_t added[SCP_MAX_ROUNDS_RECORDED]; /* rows found by the violations pass after each round */
+  double r_prim, r_dual, rho, solve_ms, max_violation;
+  double rel_step;          /* ||a_new - a_prev|| / ||a_prev|| (scp.py:157-159); -1 for QP#0 / polish */
+  double time_sec;          /* wall time of the SCP iteration */
+} scp_qp_record;
+
+typedef struct scp_solve_result {
+  int32_t n_iterations, converged, initially_feasible, feasible_at_exit, polished;
+  int32_t qp0_status;       /* not in {1, 2}: the caller raises RuntimeError("OSQP failed: ...") like scp.py:363-365 */
+  int32_t n_records;
+  int32_t first_violation_k, first_violation_i, first_violation_j;  /* of the initial check (scp.py:611-613) */
+  uint64_t first_violation; /* row id, UINT64_MAX if none */
+  double first_violation_distance;
+  double time_sec;
+} scp_solve_result;
+
+void scp_solve_default_options(scp_solve_options* o);
+/* qp_row_capacity <= 0: the default min(K pairs, max(8192, 32 N K)) (grows on demand) */
+int scp_solver_create(scp_ctx* ctx, int N, int K, int D, double h, double R, const scp_qp_settings* st,
+                      int64_t qp_row_capacity, scp_solver** out);
+void scp_solver_destroy(scp_solver* s);
+int scp_solver_update_settings(scp_solver* s, const scp_qp_settings* st);
+/* limits / space [host] as in scp_fixed_bounds; p0, v0, pf, vf [N][D] device; acc_out, pos_out, vel_out [N][K][D] device;
+ * res, records [host], record_capacity >= max_iterations + 2.  Synchronises the stream before returning. */
+int scp_solver_solve(scp_solver* s, const double* limits, const double* space, const double* p0, const double* v0,
+                     const double* pf, const double* vf, const scp_solve_options* o, double* acc_out, double* pos_out,
+                     double* vel_out, scp_solve_result* res, scp_qp_record* records, int record_capacity);
+
 /* ---- test hooks (dense K-dimension products used by the QP; exercised by tests/test_kernels_gpu.py::test_gemm_f64) ------
  * Y[R][C] = alpha * A[R][M] X[M][C] + beta * Y, row-major, device pointers. */
 int scp_gemm_f64(scp_ctx* ctx, int use_mfma, int R, int M, int C, double alpha, const double* A,

@@ -35,12 +35,14 @@ def test_library_exports_every_declared_symbol():
     with tempfile.TemporaryDirectory() as tmp:  # sizeof as the C compiler sees the header
         src = os.path.join(tmp, "sz.c")
         with open(src, "w") as f:
-            f.write('#include <stdio.h>\n#include "scp_hip.h"\nint main(void){printf("%zu %zu %zu", sizeof(scp_qp_settings), '
-                    'sizeof(scp_qp_info), sizeof(scp_pair_stats));return 0;}\n')
+            f.write('#include <stdio.h>\n#include "scp_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu", sizeof(scp_qp_settings), '
+                    'sizeof(scp_qp_info), sizeof(scp_pair_stats), sizeof(scp_solve_options), sizeof(scp_qp_record), '
+                    'sizeof(scp_solve_result));return 0;}\n')
         exe = os.path.join(tmp, "sz")
         subprocess.run(["gcc", "-I", os.path.dirname(HEADER), src, "-o", exe], check=True)
         sizes = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
-    assert [ctypes.sizeof(_hip.QpSettings), ctypes.sizeof(_hip.QpInfo), 32] == sizes, sizes
+    assert [ctypes.sizeof(_hip.QpSettings), ctypes.sizeof(_hip.QpInfo), 32, ctypes.sizeof(_hip.SolveOptions),
+            ctypes.sizeof(_hip.QpRecord), ctypes.sizeof(_hip.SolveResult)] == sizes, sizes
     s = _hip.default_settings()
     assert (s.rho, s.sigma, s.alpha, s.eps_abs, s.eps_rel, s.max_iter, s.check_termination) == (
         0.1, 1e-6, 1.6, 1e-3, 1e-3, 4000, 25)  # OSQP defaults

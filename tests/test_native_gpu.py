@@ -1,0 +1,85 @@
+"""The natively driven SCP loop (scp_solver_solve, one C call per solve: the default) against the Python-driven loop
+(native=False): the same library calls in the same order, so trajectories are bit-identical and the per-QP records
+agree field by field."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def solve(native, n, T, h, space, p0, pf, dim=2, max_iterations=15, **kw):
+    from path_planning.solvers.scp import SCP
+
+    s = SCP(n, T, h, 0.8, space, dim=dim, verbose=False, native=native, **kw)
+    s.set_initial_states(p0)
+    s.set_final_states(pf)
+    return s, s.generate_trajectories(max_iterations)
+
+
+def same_records(a, b):
+    keys = ("status_val", "iter", "rho_updates", "cg_iters_total", "working_rows", "rounds", "added", "unresolved_rows",
+            "status")
+    for k in keys:
+        assert a[k] == b[k], (k, a[k], b[k])
+    for k in ("r_prim", "r_dual", "rho", "max_violation"):
+        assert a[k] == b[k] or (np.isnan(a[k]) and np.isnan(b[k])), (k, a[k], b[k])
+
+
+@pytest.mark.parametrize("case", ["ref10", "grid64", "grid3d27", "polish", "refresh", "tiny_capacity", "single_agent"])
+def test_native_loop_is_bit_identical(case):
+    from path_planning.scenarios.position_generator import generate_grid_swap, generate_positions
+
+    kw, dim, T, h = {}, 2, 10.0, 0.2
+    if case in ("ref10", "polish", "refresh", "tiny_capacity"):
+        p0, pf = generate_positions(10, 0.8, seed=7)
+        n, space = 10, [0, 0, 20, 20]
+        kw = {"polish": {"polish": True}, "refresh": {"refresh_feasibility": True}, "tiny_capacity": {"qp_row_capacity": 4}}.get(case, {})
+    elif case == "grid64":
+        n = 64
+        p0, pf, space = generate_grid_swap(n, seed=64000)
+    elif case == "grid3d27":
+        n, dim = 27, 3
+        p0, pf, space = generate_grid_swap(n, seed=17, dim=3)
+    else:
+        n, T, h = 1, 2.0, 0.2
+        p0, pf, space = np.array([[3.0, 3.0]]), np.array([[3.05, 2.95]]), [0, 0, 20, 20]
+    a, ta = solve(True, n, T, h, space, p0, pf, dim=dim, **kw)
+    b, tb = solve(False, n, T, h, space, p0, pf, dim=dim, **kw)
+    for key in ("positions", "velocities", "accelerations"):
+        np.testing.assert_array_equal(ta[key], tb[key])
+    ia, ib = a.last_info, b.last_info
+    assert (ia["n_iterations"], ia["converged"], ia["initially_feasible"]) == (ib["n_iterations"], ib["converged"], ib["initially_feasible"])
+    assert ia["qp0"]["iter"] == ib["qp0"]["iter"] and ia["qp0"]["status_val"] == ib["qp0"]["status_val"]
+    assert len(ia["iterations"]) == len(ib["iterations"])
+    for ra, rb in zip(ia["iterations"], ib["iterations"]):
+        same_records(ra, rb)
+        assert ra["rel_step"] == rb["rel_step"] and ra["time_sec"] > 0
+    assert ("polish" in ia) == ("polish" in ib) == (case == "polish")
+    if case == "polish":
+        same_records(ia["polish"], ib["polish"])
+    if case == "tiny_capacity":
+        assert ia["iterations"][0]["working_rows"] > 4  # the QP workspace had to grow inside the native loop too
+
+
+def test_native_stdout_and_errors(capsys):
+    """The reference's printed lines (scp.py:153-163, :446-447, :611-613) and its RuntimeError come out of the native
+    loop exactly as out of the Python-driven one."""
+    from path_planning.solvers.scp import SCP
+
+    outs = []
+    for native in (True, False):
+        s = SCP(n_vehicles=3, time_horizon=3.0, time_step=0.2, min_distance=0.5, space_dims=[-5, -5, 500, 200], native=native)
+        s.set_initial_states(np.array([[-2.0, -2.0], [0.0, -2.0], [2.0, -2.0]]))
+        s.set_final_states(np.array([[2.0, 2.0], [0.0, 2.0], [-2.0, 2.0]]))
+        capsys.readouterr()
+        s.generate_trajectories(max_iterations=2)
+        out = capsys.readouterr().out.splitlines()
+        outs.append([ln for ln in out if not ln.startswith("Trajectory generation completed")])
+        assert any("Avoidance constraint violation at timestep" in ln for ln in out)
+        assert "Warning: OSQP status primal infeasible" in out and "SCP Iteration 1" in out
+        s2 = SCP(n_vehicles=2, time_horizon=1.0, time_step=0.2, min_distance=0.5, verbose=False, native=native)
+        s2.set_initial_states(np.array([[1.0, 1.0], [3.0, 3.0]]))
+        s2.set_final_states(np.array([[19.0, 19.0], [15.0, 3.0]]))
+        with pytest.raises(RuntimeError, match="OSQP failed: primal infeasible"):
+            s2.generate_trajectories()
+    assert outs[0] == outs[1]

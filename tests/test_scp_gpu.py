@@ -170,8 +170,8 @@ def test_capacity_growth_paths():
 
     p0, pf = ref_scenario(10, 7)
     ref, t_ref = solve_gpu(10, 10.0, 0.2, 0.8, [0, 0, 20, 20], p0, pf, max_iterations=3)
-    small, t_small = solve_gpu(10, 10.0, 0.2, 0.8, [0, 0, 20, 20], p0, pf, max_iterations=3, qp_row_capacity=4)
-    assert small._qp.row_capacity > 4
+    small, t_small = solve_gpu(10, 10.0, 0.2, 0.8, [0, 0, 20, 20], p0, pf, max_iterations=3, qp_row_capacity=4, native=False)
+    assert small._qp.row_capacity > 4  # (Python-driven loop; the native loop's growth path: tests/test_native_gpu.py)
     assert [i["working_rows"] for i in small.last_info["iterations"]] == [i["working_rows"] for i in ref.last_info["iterations"]]
     np.testing.assert_allclose(t_small["positions"], t_ref["positions"], rtol=0, atol=TOL)
     # selection list of the pairwise pass: capacity 8 -> grows, same (sorted) rows
@@ -343,7 +343,7 @@ def test_full_size_properties(N):
     assert rep["collision_free"] and rep["min_pair_distance"] >= 0.8 - 0.01
     # the compact rows of the LAST linearisation, spot-checked against the oracle formulas on 20 000 random rows
     prob = so.make_problem(N, K * 0.2 + 1e-9, 0.2, 0.8, space, p0, pf)
-    ctx, pp = s._ctx, s._pairs
+    ctx, pp = s._ctx, s._ensure_pairs()
     acc = ctx.tensor(traj["accelerations"])
     pos = ctx.tensor(traj["positions"])
     p0d, v0d = ctx.tensor(prob.p0), ctx.tensor(prob.v0)
@@ -410,7 +410,7 @@ def test_default_path_reaches_the_oracle_minimiser(kind, n, seed):
         p0, pf, space = generate_grid_swap(n, seed=seed)
     tight = {"eps_abs": 1e-8, "eps_rel": 1e-8, "max_iter": 40000, "max_iter0": 40000}
     s, traj = solve_gpu(n, 10.0, 0.2, 0.8, space, p0, pf, max_iterations=3, qp_settings=tight)
-    assert s._qp.settings.cg_iters == 1 and s._qp.settings.persistent == 1  # the defaults
+    assert s._native.settings.cg_iters == 1 and s._native.settings.persistent == 1  # the defaults
     prob = so.make_problem(n, 10.0, 0.2, 0.8, space, p0, pf)
     from oracle import c_oracle as co
 

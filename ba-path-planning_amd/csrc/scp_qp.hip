@@ -816,6 +816,7 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
   }
   qp->check_seq = 0;
   qp->persist_off = false;
+  qp->persist_fault = 0;
   qp->persist_cap_nW = -1;
   qp->persist_cap = 0;
   qp->persist_epoch = 0;
@@ -1153,4 +1154,20 @@ extern "C" int scp_qp_peek(scp_qp* qp, const char* name, double* out, int64_t ca
   if (n > cap) return scp_fail(ctx, SCP_ERR_CAPACITY, "qp_peek: %lld doubles needed", (long long)n);
   if (n > 0) SCP_HIP_CHECK(ctx, hipMemcpyAsync(out, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   return SCP_OK;
+}
+
+// test hook: "persist_fault" = n makes the next n persistent launches wait for a workgroup that does not exist (exercises
+// the give-up path); "persist_off" reads (value < 0) or sets whether the solver has fallen back to the three-launch
+// pipeline.  Returns the value in effect, or SCP_ERR_INVALID.
+extern "C" int scp_qp_debug_set(scp_qp* qp, const char* key, int value) {
+  if (!qp || !key) return SCP_ERR_INVALID;
+  if (!strcmp(key, "persist_fault")) {
+    if (value >= 0) qp->persist_fault = value;
+    return qp->persist_fault;
+  }
+  if (!strcmp(key, "persist_off")) {
+    if (value >= 0) qp->persist_off = value != 0;
+    return qp->persist_off ? 1 : 0;
+  }
+  return scp_fail(qp->ctx, SCP_ERR_INVALID, "qp_debug_set: unknown key %s", key);
 }

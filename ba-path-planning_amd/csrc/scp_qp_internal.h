@@ -81,6 +81,7 @@ struct scp_qp {
   double* h_scal_dev;  // the same memory as the device sees it: the check kernels write their partials straight to it
   unsigned long long check_seq;  // value the flag takes when the current check has finished
   // persistent single-step kernel (scp_qp_persist.hip)
+  int persist_fault;                 // test hook: the next n persistent launches wait for a workgroup that does not exist
   bool persist_off;                  // a launch gave up (workgroups not co-resident): stay on the three-launch pipeline
   int64_t persist_cap_nW;            // working-set size the entry capacity below was measured for (-1: none)
   int persist_cap;                   // LDS entry capacity per workgroup = most entries around any block of agents

@@ -764,11 +764,16 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
     qp->persist_cap_nW = qp->nW;
     qp->persist_cap = (m + 63) / 64 * 64;
   }
-  const size_t lds = persist_lds_bytes(K, D, qp->persist_cap, nblk);
+  // test hook (scp_qp_debug_set "persist_fault"): expect one workgroup more than is launched, so that the all-gather can
+  // never complete -- the bounded spins must time out, every workgroup must leave without writing state back, and the
+  // host must carry on with the three-launch pipeline
+  const int nblk_expected = nblk + (qp->persist_fault > 0 ? 1 : 0);
+  if (qp->persist_fault > 0) --qp->persist_fault;
+  const size_t lds = persist_lds_bytes(K, D, qp->persist_cap, nblk_expected);
   if (lds > 160 * 1024) return SCP_OK;  // too many rows around one block of agents: three-launch pipeline
   const int budget = st.max_iter - it0;  // at most this many steps in this launch
   PersistArgs a;
-  a.K = K; a.N = qp->N; a.nblk = nblk; a.ent_cap = qp->persist_cap;
+  a.K = K; a.N = qp->N; a.nblk = nblk_expected; a.ent_cap = qp->persist_cap;
   a.it0 = it0; a.max_iter = st.max_iter; a.check_every = st.check_termination;
   a.rho_interval = st.adaptive_rho_interval > 0 ? st.adaptive_rho_interval : 1;
   a.C = C;

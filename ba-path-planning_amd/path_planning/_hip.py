@@ -106,7 +106,7 @@ EXPORTS = [
     "scp_collision_violations", "scp_collision_violations_at", "scp_gather_rows", "scp_rel_step", "scp_qp_default_settings",
     "scp_qp_workspace_bytes", "scp_qp_create", "scp_qp_destroy", "scp_qp_update_settings", "scp_qp_set_problem",
     "scp_qp_reset", "scp_qp_add_rows", "scp_qp_solve", "scp_qp_clone_state", "scp_qp_get_solution",
-    "scp_qp_get_duals", "scp_gemm_f64", "scp_qp_peek",
+    "scp_qp_get_duals", "scp_gemm_f64", "scp_qp_peek", "scp_qp_debug_set",
     "scp_solve_default_options", "scp_solver_create", "scp_solver_destroy", "scp_solver_update_settings", "scp_solver_solve",
 ]
 
@@ -164,6 +164,7 @@ def load_library():
     lib.scp_qp_get_duals.argtypes = [vp, vp, vp]
     lib.scp_gemm_f64.argtypes = [vp, i32, i32, i32, i32, f64, vp, vp, f64, vp]
     lib.scp_qp_peek.argtypes = [vp, C.c_char_p, vp, i64, C.POINTER(i64)]
+    lib.scp_qp_debug_set.argtypes = [vp, C.c_char_p, i32]
     lib.scp_solve_default_options.argtypes = [C.POINTER(SolveOptions)]
     lib.scp_solve_default_options.restype = None
     lib.scp_solver_create.argtypes = [vp, i32, i32, i32, f64, f64, C.POINTER(QpSettings), i64, C.POINTER(vp)]
@@ -455,6 +456,10 @@ class QP:
         n = C.c_int64()
         self.ctx.check(self.ctx.lib.scp_qp_peek(self.h_qp, name.encode(), out.data_ptr(), cap, C.byref(n)))
         return out[: n.value]
+
+    def debug_set(self, key, value):
+        """test hook, see scp_qp_debug_set"""
+        return int(self.ctx.lib.scp_qp_debug_set(self.h_qp, key.encode(), int(value)))
 
     def duals(self):
         yf = self.ctx.empty(self.N * self.D * (4 * self.K - 1))

@@ -265,6 +265,10 @@ int scp_gemm_f64(scp_ctx* ctx, int use_mfma, int R, int M, int C, double alpha, 
  * "zc" / "yc" per working row, "gval" per incidence-list entry.  tests/test_qp_gpu.py compares the state the persistent
  * and the three-launch pipelines leave behind. */
 int scp_qp_peek(scp_qp* qp, const char* name, double* out, int64_t cap, int64_t* n_out);
+/* "persist_fault" = n: the next n persistent launches wait for a workgroup that does not exist, so their bounded spins time
+ * out (the give-up path: nothing written back, the solve continues on the three-launch pipeline); "persist_off": read
+ * (value < 0) or set whether the solver has fallen back.  Returns the value in effect. */
+int scp_qp_debug_set(scp_qp* qp, const char* key, int value);
 
 #ifdef __cplusplus
 }

@@ -285,3 +285,35 @@ def test_status_solved_inaccurate(ctx):
             hit = cap
             break
     assert hit is not None, "no iteration cap produced status 2"
+
+
+def test_persistent_kernel_give_up_falls_back(ctx):
+    """A persistent launch whose workgroups cannot all make progress (here: it is told to wait for a workgroup that does
+    not exist) must time out in its bounded spins, leave WITHOUT writing state back, and the solve must carry on from the
+    same state on the three-launch pipeline: same result as a solve that never used the persistent kernel."""
+    import torch
+    from path_planning import _hip
+
+    prob = ref_problem(10, 7)
+    x0, _, _ = qo.admm_structured(prob, st=oracle_settings(eps_abs=1e-8, eps_rel=1e-8))
+    pos, _ = so.kinematics(prob, x0)
+    eta, l_col, dist = so.linearize_pairs(prob, pos)
+    W = np.nonzero(dist - prob.R < 0.5)[0]
+    space = np.concatenate([prob.pos_min, prob.pos_max])
+    out = {}
+    for mode in ("fault", "three_launch"):
+        st = _hip.default_settings(cg_iters=1, persistent=1 if mode == "fault" else 0, max_iter=10000)
+        qp = _hip.QP(ctx, prob.N, prob.K, prob.D, prob.h, st)
+        qp.set_problem(LIMITS, space, ctx.tensor(prob.p0), ctx.tensor(prob.v0), ctx.tensor(prob.pf), ctx.tensor(prob.vf))
+        qp.reset(ctx.tensor(x0))
+        qp.add_rows(torch.as_tensor(W, dtype=torch.int64, device=ctx.tdev), ctx.tensor(eta[W]), ctx.tensor(l_col[W]))
+        if mode == "fault":
+            assert qp.debug_set("persist_fault", 1) == 1 and qp.debug_set("persist_off", -1) == 0
+        info = qp.solve()
+        if mode == "fault":
+            assert qp.debug_set("persist_off", -1) == 1 and qp.debug_set("persist_fault", -1) == 0
+        out[mode] = (info, qp.solution().cpu().numpy())
+        qp.close()
+    assert out["fault"][0]["status_val"] == out["three_launch"][0]["status_val"] == 1
+    assert out["fault"][0]["iter"] == out["three_launch"][0]["iter"]
+    np.testing.assert_array_equal(out["fault"][1], out["three_launch"][1])

@@ -59,6 +59,12 @@ static inline int scp_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b)
 // limit.  Thread safe.
 hipError_t scp_raise_lds_limit(int device, const void* kernel, size_t bytes);
 
+// Wait until a mapped host word takes the value `seq` (written by the last kernel of a check / by the persistent kernel).
+// mode 0 (default): spin -- lowest latency, one host core per waiting thread; mode 1 (scp_set_host_wait): spin for
+// ~20 us, then poll every ~20 us from a sleep, for many solver threads on few cores (compute-trajectories-batch).
+// Returns false after `timeout_s` seconds.
+bool scp_wait_host_word(volatile unsigned long long* word, unsigned long long seq, int timeout_s);
+
 // ---- internal launchers (time-major device layout [K][C], C = N*D) --------------------------------
 // Y[R][C] = alpha * A[R][M] X[M][C] + beta * Y   (row-major; A small and L2 resident)
 int scp_launch_gemm(scp_ctx* ctx, int use_mfma, int R, int M, int C, double alpha, const double* A,

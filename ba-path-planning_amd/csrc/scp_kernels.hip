@@ -3,6 +3,10 @@
 // Reference: /root/reference/src/path_planning/solvers/scp.py (line numbers cited per kernel).
 #include "scp_common.h"
 
+#include <time.h>
+
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <map>
@@ -60,6 +64,32 @@ hipError_t scp_raise_lds_limit(int device, const void* kernel, size_t bytes) {
   const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e == hipSuccess) have = bytes;
   return e;
+}
+
+static std::atomic<int> g_host_wait_mode{0};
+
+extern "C" void scp_set_host_wait(int mode) { g_host_wait_mode.store(mode == 1 ? 1 : 0, std::memory_order_relaxed); }
+
+bool scp_wait_host_word(volatile unsigned long long* word, unsigned long long seq, int timeout_s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const bool sleepy = g_host_wait_mode.load(std::memory_order_relaxed) == 1;
+  unsigned spins = 0;
+  while (*word != seq) {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+    ++spins;
+    if (sleepy && spins > 2000) {  // ~20 us of spinning: the kernel is a long one, give the core away
+      struct timespec ts = {0, 20000};
+      nanosleep(&ts, nullptr);
+      if ((spins & 0x3FF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s)) break;
+    } else if ((spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s)) {
+      break;
+    }
+  }
+  const bool ok = *word == seq;
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return ok;
 }
 
 extern "C" const char* scp_last_error(const scp_ctx* ctx) { return ctx ? ctx->err : "null context"; }

@@ -10,9 +10,6 @@
 // An ADMM step with n PCG steps is 4n + 3 launches, 7 at the default n = 1 (15n + ... on the generic path of scp_qp.hip, which stays as the fallback
 // for K > 128 and as the use_mfma = 0/2 reference); the arithmetic is the same, statement by statement.
 #include "scp_qp_device.h"
-#include <sched.h>
-
-#include <chrono>
 #include <cstdlib>
 
 namespace {
@@ -1253,21 +1250,25 @@ __device__ inline int dpp_mov0_i32(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true);
 }
 __global__ __launch_bounds__(1024) void csr_scan_kernel(int ncell, int* __restrict__ ptr, int* __restrict__ cur) {
-  // 4 consecutive cells per thread and pass: 4096 cells per pass
+  // SC consecutive cells per thread and pass (16 384 cells per pass: 51 200 cells in 4 passes; a pass costs one
+  // memory round trip + two barriers whatever its width -- 4 cells per thread took 38 us at N K = 51 200)
+  constexpr int SC = 16;
   __shared__ int wsum[16];
   __shared__ int carry_s;
   if (threadIdx.x == 0) carry_s = 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  auto load4 = [&](int c, int (&v)[4]) {
+  auto loadn = [&](int c, int (&v)[SC]) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = c + e < ncell ? ptr[c + e] : 0;
+    for (int e = 0; e < SC; ++e) v[e] = c + e < ncell ? ptr[c + e] : 0;
   };
-  int v[4], vn[4];
-  load4(4 * (int)threadIdx.x, v);
-  for (int b0 = 0; b0 < ncell; b0 += 4096) {
-    const int c = b0 + 4 * (int)threadIdx.x;
-    load4(c + 4096, vn);  // (cells of a later pass: not written yet)
-    const int tot = (v[0] + v[1]) + (v[2] + v[3]);
+  int v[SC], vn[SC];
+  loadn(SC * (int)threadIdx.x, v);
+  for (int b0 = 0; b0 < ncell; b0 += SC * 1024) {
+    const int c = b0 + SC * (int)threadIdx.x;
+    loadn(c + SC * 1024, vn);  // (cells of a later pass: not written yet)
+    int tot = 0;
+#pragma unroll
+    for (int e = 0; e < SC; ++e) tot += v[e];
     int incl = tot;
     incl += dpp_mov0_i32<0x111, 0xF>(incl);
     incl += dpp_mov0_i32<0x112, 0xF>(incl);
@@ -1281,7 +1282,7 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int ncell, int* __restri
     for (int w = 0; w < wave; ++w) base += wsum[w];
     int run = base + incl - tot;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < SC; ++e) {
       if (c + e < ncell) {
         ptr[c + e] = run;
         cur[c + e] = run;
@@ -1291,7 +1292,7 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int ncell, int* __restri
     __syncthreads();
     if (threadIdx.x == 1023) carry_s = base + incl;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = vn[e];
+    for (int e = 0; e < SC; ++e) v[e] = vn[e];
   }
   __syncthreads();
   if (threadIdx.x == 0) ptr[ncell] = carry_s;
@@ -1747,16 +1748,7 @@ int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
                      seq);
   FUSED_LAUNCHED(qp);
   {
-    const auto t0 = std::chrono::steady_clock::now();
-    unsigned spins = 0;
-    while (*flag != seq) {
-#if defined(__x86_64__) || defined(__i386__)
-      __builtin_ia32_pause();
-#endif
-      if ((spins & 0x3F) == 0x3F) sched_yield();  // many solver threads may share the host's cores (batch CLI)
-      if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
-    }
-    if (*flag != seq) SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // a fault surfaces here
+    if (!scp_wait_host_word(flag, seq, 20)) SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // a fault surfaces here
     if (*flag != seq) return scp_fail(ctx, SCP_ERR_HIP, "fused check: completion flag not written");
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
   }

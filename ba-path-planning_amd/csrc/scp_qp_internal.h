@@ -83,8 +83,8 @@ struct scp_qp {
   // persistent single-step kernel (scp_qp_persist.hip)
   int persist_fault;                 // test hook: the next n persistent launches wait for a workgroup that does not exist
   bool persist_off;                  // a launch gave up (workgroups not co-resident): stay on the three-launch pipeline
-  int64_t persist_cap_nW;            // working-set size the entry capacity below was measured for (-1: none)
-  int persist_cap;                   // LDS entry capacity per workgroup = most entries around any block of agents
+  int64_t persist_cap_nW;            // working-set size that overflowed the LDS entry tables (-1: none): not tried again
+  int persist_cap;                   // LDS entry capacity per workgroup (all the LDS that is left)
   unsigned long long persist_epoch;  // ADMM steps run by persistent launches so far: the step tags of the granules never repeat
   unsigned* h_persist;               // mapped host words written by the kernel: [0] exit code, [1] iterations done
   unsigned* h_persist_dev;

@@ -25,9 +25,6 @@
 // state back, and the host repeats the iterations on the three-launch pipeline.
 #include "scp_qp_device.h"
 
-#include <sched.h>
-
-#include <chrono>
 
 namespace {
 using namespace scpdev;
@@ -74,7 +71,7 @@ struct PersistArgs {
 };
 
 // why the kernel returned (host_status[0]); the host re-derives every decision from the nine check results
-enum { EXIT_SOLVED = 1, EXIT_GAVE_UP = 2, EXIT_MAX_ITER = 3, EXIT_INFEASIBLE = 4, EXIT_RHO = 5 };
+enum { EXIT_SOLVED = 1, EXIT_GAVE_UP = 2, EXIT_MAX_ITER = 3, EXIT_INFEASIBLE = 4, EXIT_RHO = 5, EXIT_OVERFLOW = 6 };
 constexpr int NCHK = 9;  // rp, |Ax|, |z|, rd, |Px|, |A^T y|, |dy|, supp (a sum), |A^T dy|  (maxima of non-negative values)
 constexpr int CK_RP = 0, CK_NAX = 1, CK_NZ = 2, CK_RD = 3, CK_NPX = 4, CK_NATY = 5, CK_NDY = 6, CK_SUPP = 7, CK_NATDY = 8;
 
@@ -150,13 +147,21 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
   const int a1 = min(a0 + APB, N);
   const int ebase = A.cell_ptr[cell_of(0, a0, K)];
   const int ne = A.cell_ptr[cell_of(0, a1, K)] - ebase;
-  if (ne > cap) {  // cannot happen when the host sized the launch from the entry counts; never spin on it
-    if (threadIdx.x == 0) {
-      __hip_atomic_store(A.give_up, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(A.host_status, (unsigned)EXIT_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(A.host_flag, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // More incident rows around some block of agents than the LDS tables hold: EVERY workgroup finds that out by itself
+  // (the largest block's count, a few loads) and leaves before anything is published -- nobody spins on anybody.
+  {
+    int worst = 0;
+    for (int b = threadIdx.x; b < (N + APB - 1) / APB; b += NT) {
+      const int b0 = b * APB, b1 = min(b0 + APB, N);
+      worst = max(worst, A.cell_ptr[cell_of(0, b1, K)] - A.cell_ptr[cell_of(0, b0, K)]);
     }
-    return;
+    if (__syncthreads_or(worst > cap)) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        __hip_atomic_store(A.host_status, (unsigned)EXIT_OVERFLOW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(A.host_flag, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
   }
   if (threadIdx.x == 0) fail_s = 0;
   for (int i = threadIdx.x; i <= (a1 - a0) * K; i += NT) cptr[i] = A.cell_ptr[cell_of(0, a0, K) + i] - ebase;
@@ -703,19 +708,6 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
   }
 }
 
-// largest number of incidence-list entries of any block of `apb` consecutive agents -> out[0]
-__global__ __launch_bounds__(256) void max_block_entries_kernel(int N, int K, int apb, const int* __restrict__ cell_ptr,
-                                                                 int* __restrict__ out) {
-  const int nblk = (N + apb - 1) / apb;
-  int m = 0;
-  for (int b = blockIdx.x * 256 + threadIdx.x; b < nblk; b += gridDim.x * 256) {
-    const int a0 = b * apb, a1 = min(a0 + apb, N);
-    m = max(m, cell_ptr[cell_of(0, a1, K)] - cell_ptr[cell_of(0, a0, K)]);
-  }
-  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
-}
-
 size_t persist_lds_bytes(int K, int D, int cap, int nblk) {
   const int apb = CB / D;
   size_t dbl = (size_t)3 * CB * pad_col(K) + (size_t)apb * 64 * D + (size_t)NCHK * nblk + (size_t)cap * (4 * D + 4);
@@ -754,15 +746,17 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
     int rc = scp_qp_cg1_prepare(qp);
     if (rc) return rc;
   }
-  if (qp->persist_cap_nW != qp->nW) {  // working set changed: size the entry tables (one read-back per change)
-    SCP_HIP_CHECK(ctx, hipMemsetAsync(d.sync_words + 2, 0, 16, s));
-    hipLaunchKernelGGL(max_block_entries_kernel, dim3(4), dim3(256), 0, s, qp->N, K, apb, d.cell_ptr, (int*)(d.sync_words + 2));
-    SCP_HIP_CHECK(ctx, hipGetLastError());
-    int m = 0;
-    SCP_HIP_CHECK(ctx, hipMemcpyAsync(&m, d.sync_words + 2, sizeof(int), hipMemcpyDeviceToHost, s));
-    SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));
-    qp->persist_cap_nW = qp->nW;
-    qp->persist_cap = (m + 63) / 64 * 64;
+  // Entry tables: the workgroup is alone on its CU anyway (228 VGPRs x 8 waves), so it simply takes all the LDS there is
+  // -- no read-back of the largest block's entry count.  A block of agents with more incident rows than fit (> ~1300 at
+  // K = 50) makes the kernel leave at once with EXIT_OVERFLOW; that working set then runs on the three-launch pipeline.
+  if (qp->persist_cap_nW == qp->nW) return SCP_OK;  // this working set overflowed before
+  {
+    const int nb = nblk + 1;  // (+1: the fault-injection hook below may announce one more workgroup)
+    const size_t fixed = persist_lds_bytes(K, D, 0, nb);
+    const size_t per_entry = (size_t)(4 * D + 4) * sizeof(double) + 3 * sizeof(int);
+    const size_t budget_lds = 160 * 1024 - 1024;  // minus the static __shared__ of the kernel (580 B)
+    if (fixed + 64 * per_entry > budget_lds) return SCP_OK;
+    qp->persist_cap = (int)((budget_lds - fixed) / per_entry / 64 * 64);
   }
   // test hook (scp_qp_debug_set "persist_fault"): expect one workgroup more than is launched, so that the all-gather can
   // never complete -- the bounded spins must time out, every workgroup must leave without writing state back, and the
@@ -820,21 +814,17 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   *ran = 1;
   {
     volatile u64* flag = (volatile u64*)(qp->h_scal + SL_COUNT + SCP_RESID_CAP);
-    const auto t0 = std::chrono::steady_clock::now();
-    unsigned spins = 0;
-    while (*flag != a.seq) {
-#if defined(__x86_64__) || defined(__i386__)
-      __builtin_ia32_pause();
-#endif
-      if ((spins & 0x3F) == 0x3F) sched_yield();  // many solver threads may share the host's cores (batch CLI)
-      if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) break;
-    }
-    if (*flag != a.seq) SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // a fault surfaces here
+    if (!scp_wait_host_word(flag, a.seq, 30)) SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // a fault surfaces here
     if (*flag != a.seq) return scp_fail(ctx, SCP_ERR_HIP, "persistent kernel: completion word not written");
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
   }
   *code = (int)((volatile unsigned*)qp->h_persist)[0];
   *it_done = (int)((volatile unsigned*)qp->h_persist)[1];
+  if (*code == EXIT_OVERFLOW) {  // nothing ran, nothing was published: this working set stays on the three-launch pipeline
+    qp->persist_cap_nW = qp->nW;
+    *ran = 0;
+    return SCP_OK;
+  }
   if (*code != SCP_PERSIST_GAVE_UP) qp->persist_epoch += (u64)(*it_done - it0);  // one tag per ADMM step
   return SCP_OK;
 }

@@ -100,7 +100,7 @@ class QpInfo(C.Structure):
 
 
 EXPORTS = [
-    "scp_abi_version", "scp_ctx_create", "scp_ctx_destroy", "scp_last_error", "scp_ctx_synchronize",
+    "scp_set_host_wait", "scp_abi_version", "scp_ctx_create", "scp_ctx_destroy", "scp_last_error", "scp_ctx_synchronize",
     "scp_ctx_last_pair_ms",
     "scp_kinematics", "scp_fixed_bounds", "scp_linearize_pairs", "scp_check_avoidance",
     "scp_collision_violations", "scp_collision_violations_at", "scp_gather_rows", "scp_rel_step", "scp_qp_default_settings",
@@ -132,6 +132,8 @@ def load_library():
     vp, i32, i64, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
     pd = C.POINTER(C.c_double)
     lib.scp_abi_version.restype = i32
+    lib.scp_set_host_wait.argtypes = [i32]
+    lib.scp_set_host_wait.restype = None
     lib.scp_ctx_create.argtypes = [i32, vp, C.POINTER(vp)]
     lib.scp_ctx_destroy.argtypes = [vp]
     lib.scp_ctx_destroy.restype = None

@@ -209,6 +209,11 @@ def main(argv=None):
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.streams > 1 or world > 1:
+        # many solver threads / processes on the host's cores: waiting threads sleep between polls instead of spinning
+        from .. import _hip
+
+        _hip.load_library().scp_set_host_wait(1)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         # more ranks than GPUs is a feature: launches of one process serialise in the HIP runtime (8 streams in ONE
@@ -266,6 +271,11 @@ def main(argv=None):
         print(f"  [rank {rank}] N={N} trial {trial+1:02d}/{cfg['trials_per_N']}  time = {res['time_sec']:.3f}s  [{status_str}]")
         return res
 
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()  # all ranks start their timed loops together (scenario generation takes different times)
+    wall_start = time.time()
     t_all = time.perf_counter()
     if args.streams <= 1:
         runs = [one_job(j) for j in jobs]
@@ -293,12 +303,17 @@ def main(argv=None):
         print(f"  [rank {rank}] {len(jobs)} scenarios in {wall:.2f}s wall = {len(jobs)/wall:.1f} scenarios/s "
               f"({args.streams} stream(s); scenario generation {t_gen:.2f}s before the clock)")
 
+    wall_end = time.time()
     if world > 1:
         import torch.distributed as dist
 
         gathered = [None] * world
-        dist.all_gather_object(gathered, runs)
-        runs = [r for part in gathered for r in part]
+        dist.all_gather_object(gathered, (runs, wall_start, wall_end))
+        runs = [r for part in gathered for r in part[0]]
+        span = max(g[2] for g in gathered) - min(g[1] for g in gathered)
+        if rank == 0 and runs:
+            print(f"  [all {world} ranks] {len(runs)} scenarios in {span:.2f}s (first start to last end) = "
+                  f"{len(runs)/span:.1f} scenarios/s")
     if rank != 0:
         return None
     runs.sort(key=lambda r: (cfg["Ns"].index(r["N"]), r["trial_index"]))

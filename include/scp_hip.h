@@ -94,6 +94,9 @@ typedef struct scp_qp_info {
 } scp_qp_info;
 
 int scp_abi_version(void);
+/* How host threads wait for a kernel's completion word (process-wide): 0 = spin (default: lowest latency, one core per
+ * waiting thread), 1 = spin ~20 us, then poll from 20 us sleeps (many solver threads on few cores). */
+void scp_set_host_wait(int mode);
 
 /* Plane stride (in doubles) of the SoA eta array of scp_linearize_pairs: K*nq rounded up to an even count so
  * that every plane starts 16-byte aligned. */

@@ -375,25 +375,30 @@ __global__ __launch_bounds__(1024) void spd_inverse_lds_kernel(int K, const doub
     for (int r = ty; r < K; r += TY) Minv[r * K + tx] = aug[r * W + K + tx];
 }
 
-// Gauss-Jordan inverse of the SPD matrix held in aug = [Hf | I] (K x 2K, global memory, one workgroup).
-__global__ __launch_bounds__(1024) void spd_inverse_kernel(int K, double* __restrict__ aug, double* __restrict__ Minv) {
-  extern __shared__ double sh[];  // prow[2K] | col[K]
-  double* prow = sh;
-  double* col = sh + 2 * K;
+// Gauss-Jordan inverse for K > SCP_INV_LDS_MAX_K, two small launches per pivot over the whole chip: the pivot row (scaled)
+// and the pivot column are first copied out, then every element of aug = [Hf | I] is updated from them -- the same
+// operation per element as the one-workgroup kernels (bit-identical result), but a pivot's K x 2K update is spread over
+// all CUs instead of dragging the 4 MB matrix (K = 500) through one CU 500 times (61 ms -> ~3 ms per inverse; the
+// reference's demo, K = 500, spent 88 % of its 0.65 s there).
+__global__ __launch_bounds__(256) void gj_extract_kernel(int K, int p, const double* __restrict__ aug, double* __restrict__ prow,
+                                                          double* __restrict__ pcol) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
   const int W = 2 * K;
-  for (int p = 0; p < K; ++p) {
-    const double piv = aug[(int64_t)p * W + p];
-    for (int c = threadIdx.x; c < W; c += blockDim.x) prow[c] = aug[(int64_t)p * W + c] / piv;
-    for (int r = threadIdx.x; r < K; r += blockDim.x) col[r] = aug[(int64_t)r * W + p];
-    __syncthreads();
-    for (int e = threadIdx.x; e < K * W; e += blockDim.x) {
-      const int r = e / W, c = e % W;
-      if (r == p) aug[e] = prow[c];
-      else aug[e] -= col[r] * prow[c];
-    }
-    __syncthreads();
-  }
-  for (int e = threadIdx.x; e < K * K; e += blockDim.x) Minv[e] = aug[(int64_t)(e / K) * W + K + (e % K)];
+  if (t < W) prow[t] = aug[(int64_t)p * W + t] / aug[(int64_t)p * W + p];
+  else if (t - W < K) pcol[t - W] = aug[(int64_t)(t - W) * W + p];
+}
+__global__ __launch_bounds__(256) void gj_update_kernel(int K, int p, double* __restrict__ aug, const double* __restrict__ prow,
+                                                         const double* __restrict__ pcol) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int W = 2 * K;
+  if (e >= (int64_t)K * W) return;
+  const int r = (int)(e / W), c = (int)(e % W);
+  if (r == p) aug[e] = prow[c];
+  else aug[e] -= pcol[r] * prow[c];
+}
+__global__ __launch_bounds__(256) void gj_finish_kernel(int K, const double* __restrict__ aug, double* __restrict__ Minv) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < K * K) Minv[t] = aug[(int64_t)(t / K) * 2 * K + K + (t % K)];
 }
 
 // append working rows: decode (k, i, j), copy eta / l, z = max(A x, l), y = 0
@@ -466,6 +471,7 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.S0t = c.take<double>((size_t)K * K);
   d.HS = d.Hf = d.Minv = nullptr;  // rho-dependent blocks live in the cache slots (carve_kkt_slots), set by build_kkt
   d.aug = c.take<double>((size_t)2 * K * K);
+  d.gj_tmp = c.take<double>((size_t)3 * K);
   d.wrow = c.take<double>((size_t)Rf);
   d.G0 = c.take<double>((size_t)K * K);
   d.pF = c.take<double>(scp_packed_count(Rf, K));
@@ -602,7 +608,13 @@ int build_kkt(scp_qp* qp) {
       SCP_HIP_CHECK(qp->ctx, scp_raise_lds_limit(qp->ctx->device, reinterpret_cast<const void*>(spd_inverse_lds_kernel), lds));
     hipLaunchKernelGGL(spd_inverse_lds_kernel, dim3(1), dim3(1024), lds, s, K, d.Hf, d.Minv);
   } else {
-    hipLaunchKernelGGL(spd_inverse_kernel, dim3(1), dim3(1024), (size_t)3 * K * sizeof(double), s, K, d.aug, d.Minv);
+    double* prow = d.gj_tmp;
+    double* pcol = d.gj_tmp + 2 * K;
+    for (int p = 0; p < K; ++p) {
+      hipLaunchKernelGGL(gj_extract_kernel, grid1((int64_t)3 * K), dim3(256), 0, s, K, p, d.aug, prow, pcol);
+      hipLaunchKernelGGL(gj_update_kernel, grid1((int64_t)K * 2 * K), dim3(256), 0, s, K, p, d.aug, prow, pcol);
+    }
+    hipLaunchKernelGGL(gj_finish_kernel, grid1((int64_t)K * K), dim3(256), 0, s, K, d.aug, d.Minv);
   }
   QP_LAUNCHED(qp);
   // T = S0 H_f^{-1}: the persistent kernel forms S0 p = T r on spare matrix-core waves next to p = H_f^{-1} r
@@ -962,6 +974,10 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
     // launch; the persistent single-step kernel goes further and runs the checks itself, returning only when the host has
     // something to decide (solved, infeasible, iteration limit, a rho update)
     const bool qp0_it = fused && qp->nW == 0;
+    // long horizons (K in 121..1024, e.g. the reference's demo K = 500): the same single-step pipeline with
+    // cg1_colK_kernel as its column kernel; its termination check is the generic one (snapshot of the duals)
+    const bool bigk = st.use_mfma == 1 && qp->K > SCP_FUSED_MAX_K && qp->K <= SCP_BIGK_MAX_K && qp->C <= SCP_PART_CAP / 2;
+    const bool cg1_big = bigk && st.cg_iters == 1 && qp->nW > 0;
     const bool cg1_it = fused && st.cg_iters == 1 && qp->nW > 0;  // its update kernel emits delta-y itself
     bool persist_done = false;
     if (cg1_it && scp_qp_persist_eligible(qp)) {
@@ -996,6 +1012,7 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
                                             hipMemcpyDeviceToDevice, ctx->stream));
       }
       if (cg1_it) QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total, with_dy));
+      else if (cg1_big) QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total, false));
       else if (qp0_it) QP_CHECK(scp_qp_qp0_iterations(qp, n_it, with_dy ? qp->d.dyf : nullptr));
       else if (fused) QP_CHECK(scp_qp_fused_iteration(qp, &cg_total));
       else QP_CHECK(admm_iteration(qp, &cg_total));
@@ -1008,7 +1025,7 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
       } else {
         QP_CHECK(residuals(qp, with_dy));
       }
-      if (!cg1_it) qp->cg1_ready = false;  // residuals() used G and the Q slabs as scratch (the fused check keeps
+      if (!cg1_it) { qp->cg1_ready = false; qp->qx_fresh = false; }  // residuals() used G and the Q slabs as scratch (the fused check keeps
                                            // the pipeline's carried state and refreshes S0 x, F x exactly)
       const double* hs = qp->h_scal;
       rp = hs[SL_RP];

@@ -658,6 +658,105 @@ __global__ __launch_bounds__(FT) void cg1_col_kernel(int K, int Rf, int64_t C, d
   PHASE_MARK(5);
 }
 
+// ---- the column kernel for long horizons (K > SCP_FUSED_MAX_K, up to 1024: the reference's demo runs K = 500) ------------
+// Same quantities as cg1_col_kernel -- r by reverse cumulative sums, p = H_f^{-1} r, S0 p, F p by forward sums, r.p -- with
+// ONE WORKGROUP PER COLUMN and one thread per time step: the sums are block-wide scans (wave scans on DPP + one LDS
+// round for the wave totals), and H_f^{-1} (2 MB at K = 500, symmetric: thread k reads column k = row k, coalesced over
+// the threads) is streamed from L2 by every column's workgroup instead of living in MFMA operand registers.  No LDS tiles
+// of 4K-1 rows x 16 columns, so K is bounded by the thread count only.
+__device__ inline double block_scan_incl(double v, bool reverse, double* wtot) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+  const double w = reverse ? wave_incl_rsum(v) : wave_incl_sum(v);
+  if (lane == (reverse ? 0 : 63)) wtot[wave] = w;
+  __syncthreads();
+  double off = 0.0;
+  if (reverse) {
+    for (int q = nw - 1; q > wave; --q) off += wtot[q];
+  } else {
+    for (int q = 0; q < wave; ++q) off += wtot[q];
+  }
+  __syncthreads();
+  return w + off;
+}
+// value of thread k + shift (0 outside [0, K)) through an LDS line
+__device__ inline double block_shift(double v, int shift, int K, double* line) {
+  const int k = threadIdx.x;
+  if (k < K) line[k] = v;
+  __syncthreads();
+  const int src = k + shift;
+  const double out = (k < K && src >= 0 && src < K) ? line[src] : 0.0;
+  __syncthreads();
+  return out;
+}
+
+__global__ __launch_bounds__(1024) void cg1_colK_kernel(int K, int Rf, int64_t C, double rho, double h,
+                                                         const double* __restrict__ Minv, const double* __restrict__ wrow,
+                                                         const double* __restrict__ x, const double* __restrict__ Fx,
+                                                         const double* __restrict__ zf, const double* __restrict__ yf, int N,
+                                                         int D, const int* __restrict__ cell_ptr,
+                                                         const double* __restrict__ coef, const double* __restrict__ gval,
+                                                         double* __restrict__ p, double* __restrict__ Qp,
+                                                         double* __restrict__ Fp, double* __restrict__ part_rz) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* rbuf = lds;        // [K] r
+  double* line = rbuf + K;   // [K] neighbour shifts
+  __shared__ double wtot[16];
+  const int col = blockIdx.x, k = threadIdx.x;
+  const bool live = k < K;
+  const int agent = col / D, dd = col - agent * D;
+  const double hh = h * h;
+  double wj = 0.0, wa = 0.0, wv = 0.0, wp = 0.0, xk = 0.0, g = 0.0;
+  if (live) {
+    auto wprime = [&](int row) {
+      const int64_t o = (int64_t)row * C + col;
+      return rho * wrow[row] * (zf[o] - Fx[o]) - yf[o];
+    };
+    if (k < K - 1) wj = wprime(k);
+    wa = wprime(K - 1 + k);
+    wv = wprime(2 * K - 1 + k);
+    wp = wprime(3 * K - 1 + k);
+    xk = x[(int64_t)k * C + col];
+    const int c0 = cell_ptr[cell_of(k, agent, K)], c1 = cell_ptr[cell_of(k, agent, K) + 1];
+    for (int t = c0; t < c1; ++t) g += coef[(size_t)t * D + dd] * gval[t];
+  }
+  const double u1 = h * wv + 0.5 * hh * (wp - g);
+  const double u2 = wp + g;
+  const double d1 = block_scan_incl(u1, true, wtot);
+  const double s1 = block_scan_incl(u2, true, wtot);
+  const double d2 = block_shift(block_scan_incl(s1, true, wtot), +1, K, line);  // exclusive suffix sum
+  const double wjm = block_shift(wj, -1, K, line);                               // w_j[k - 1]
+  const double rk = (((wjm - wj) / h + wa) + (d1 + 0.5 * hh * g) + hh * d2) - 2.0 * xk;
+  if (live) rbuf[k] = rk;
+  __syncthreads();
+  double pk = 0.0;
+  if (live) {  // p_k = sum_m Minv[m][k] r_m  (Minv symmetric: column k read as the k-th entries of its rows -> coalesced)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int m = 0;
+    for (; m + 4 <= K; m += 4) {
+      a0 = fma(Minv[(size_t)m * K + k], rbuf[m], a0);
+      a1 = fma(Minv[(size_t)(m + 1) * K + k], rbuf[m + 1], a1);
+      a2 = fma(Minv[(size_t)(m + 2) * K + k], rbuf[m + 2], a2);
+      a3 = fma(Minv[(size_t)(m + 3) * K + k], rbuf[m + 3], a3);
+    }
+    for (; m < K; ++m) a0 = fma(Minv[(size_t)m * K + k], rbuf[m], a0);
+    pk = (a0 + a1) + (a2 + a3);
+  }
+  const double c1s = block_scan_incl(pk, false, wtot);                                // csum(p)
+  const double c2s = block_shift(block_scan_incl(c1s, false, wtot), -1, K, line);     // csum_excl(csum(p))
+  const double c1p = block_shift(c1s, -1, K, line);
+  const double pn = block_shift(pk, +1, K, line);
+  const double rz = block_scan_incl(live ? rk * pk : 0.0, false, wtot);  // total in the last thread
+  if (live) {
+    p[(int64_t)k * C + col] = pk;
+    Qp[(int64_t)k * C + col] = hh * (c2s - 0.5 * c1p);
+    if (k < K - 1) Fp[(int64_t)k * C + col] = (pn - pk) / h;
+    Fp[(int64_t)(K - 1 + k) * C + col] = pk;
+    Fp[(int64_t)(2 * K - 1 + k) * C + col] = h * c1s;
+    Fp[(int64_t)(3 * K - 1 + k) * C + col] = hh * (c2s + 0.5 * c1s);
+  }
+  if (threadIdx.x == blockDim.x - 1) part_rz[col] = rz;
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void cg1_rows_sq_kernel(int64_t nW, int64_t C, double rho, const int* __restrict__ wk,
                                                            const int* __restrict__ wi, const int* __restrict__ wj,
@@ -893,7 +992,7 @@ constexpr int UPD_RPT = 2;  // slab rows per thread in the elementwise part of c
 // new S0 x formed on the fly from (S0 x, S0 p) with the same fma, z/y update, then the row values of the NEXT
 // right-hand side   g = rho zc - yc - rho eta.d(S0 x)      (A_W^T g is gathered by cg1_col_kernel).
 template <int D>
-__global__ __launch_bounds__(256) void cg1_update_kernel(int K, int Rf, int64_t C, int nblk, int eblocks, int nblk8, double rho,
+__global__ __launch_bounds__(256) void cg1_update_kernel(int K, int Rf, int64_t C, int nblk, int npart, int eblocks, int nblk8, double rho,
                                                           double rho_c, double alpha, const double* __restrict__ part_rz,
                                                           const double* __restrict__ part_sq,
                                                           const double* __restrict__ wrow, const double* __restrict__ lf,
@@ -930,8 +1029,8 @@ __global__ __launch_bounds__(256) void cg1_update_kernel(int K, int Rf, int64_t 
         v0[u] = x[g]; v1[u] = pdir[g]; v2[u] = Qx[g]; v3[u] = Qp[g];
       }
     }
-    const double a = inline_sq ? step_length_inline_256<D>(part_rz, nblk, nW, C, rho_c, wk, wi, wj, weta, Qp)
-                               : step_length_256(part_rz, nblk, part_sq);
+    const double a = inline_sq ? step_length_inline_256<D>(part_rz, npart, nW, C, rho_c, wk, wi, wj, weta, Qp)
+                               : step_length_256(part_rz, npart, part_sq);
     const double aa = alpha * a;
     if (!live) return;
 #pragma unroll
@@ -970,8 +1069,8 @@ __global__ __launch_bounds__(256) void cg1_update_kernel(int K, int Rf, int64_t 
     z = zc[n]; y = yc[n]; lo = wl[n];
     posi = pos_i[n]; posj = pos_j[n];
   }
-  const double a = inline_sq ? step_length_inline_256<D>(part_rz, nblk, nW, C, rho_c, wk, wi, wj, weta, Qp)
-                             : step_length_256(part_rz, nblk, part_sq);
+  const double a = inline_sq ? step_length_inline_256<D>(part_rz, npart, nW, C, rho_c, wk, wi, wj, weta, Qp)
+                             : step_length_256(part_rz, npart, part_sq);
   const double aa = alpha * a;
   if (!live) return;
   double tc = 0.0, ax = 0.0;
@@ -1188,7 +1287,13 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count, bool emit_dy) {
   double* Qx = qp->qx_sel ? d.HQ : d.HQ + nx;  // S0 x (carried)
   double* Qn = qp->qx_sel ? d.HQ + nx : d.HQ;  // S0 x of the next iteration
   const size_t lds = (size_t)CB * (pad_col(Rf) + 5 * pad_col(K)) * sizeof(double);
-  if (K <= 64) {
+  int npart = nblk;  // partial sums of r.p: one per column block, or one per column (long horizons)
+  if (K > SCP_FUSED_MAX_K) {
+    npart = (int)C;
+    hipLaunchKernelGGL(cg1_colK_kernel, dim3((unsigned)C), dim3((unsigned)((K + 63) / 64 * 64)), (size_t)2 * K * sizeof(double), s, K, Rf,
+                       C, qp->rho, qp->h, d.Minv, d.wrow, d.x, d.fx, d.zf, d.yf, qp->N, qp->D, d.cell_ptr, d.coef, d.gval, d.p,
+                       Qp, Fp, part_rz);
+  } else if (K <= 64) {
     int rc = allow_lds(qp, cg1_col_kernel<1>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(cg1_col_kernel<1>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->rho, qp->h, d.pMinv, d.wrow, d.x, d.fx,
@@ -1215,11 +1320,11 @@ int scp_qp_cg1_iteration(scp_qp* qp, int* cg_count, bool emit_dy) {
   const int eblocks = nblk8 * ((Rf + K + 16 * UPD_RPT - 1) / (16 * UPD_RPT));
   const dim3 ugrid((unsigned)(eblocks + (qp->nW + 255) / 256));
   if (qp->D == 2)
-    hipLaunchKernelGGL(cg1_update_kernel<2>, ugrid, rblock, 0, s, K, Rf, C, nblk, eblocks, nblk8, qp->rho, rho_c, qp->st.alpha,
+    hipLaunchKernelGGL(cg1_update_kernel<2>, ugrid, rblock, 0, s, K, Rf, C, nblk, npart, eblocks, nblk8, qp->rho, rho_c, qp->st.alpha,
                        part_rz, part_sq, d.wrow, d.lf, d.uf, d.zf, d.yf, d.fx, Fp, d.x, d.p, Qp, Qx, Qn, qp->nW, d.w_k,
                        d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc, d.pos_i, d.pos_j, d.gval, dyf, dyc, inline_sq);
   else
-    hipLaunchKernelGGL(cg1_update_kernel<3>, ugrid, rblock, 0, s, K, Rf, C, nblk, eblocks, nblk8, qp->rho, rho_c, qp->st.alpha,
+    hipLaunchKernelGGL(cg1_update_kernel<3>, ugrid, rblock, 0, s, K, Rf, C, nblk, npart, eblocks, nblk8, qp->rho, rho_c, qp->st.alpha,
                        part_rz, part_sq, d.wrow, d.lf, d.uf, d.zf, d.yf, d.fx, Fp, d.x, d.p, Qp, Qx, Qn, qp->nW, d.w_k,
                        d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc, d.pos_i, d.pos_j, d.gval, dyf, dyc, inline_sq);
   FUSED_LAUNCHED(qp);

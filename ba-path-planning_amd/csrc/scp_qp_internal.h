@@ -15,6 +15,7 @@ enum Slot {  // device scalar slots (doubles)
 struct QpDev {
   // constant blocks
   double *F, *Ft, *S0, *S0t, *HS, *Hf, *Minv, *aug, *wrow;
+  double* gj_tmp;  // [3K]: pivot row and column of the per-pivot Gauss-Jordan launches (K > SCP_INV_LDS_MAX_K)
   double* G0;  // [K][K]: F^T w F (constant; H_f = (2 + sigma) I + rho G0)
   // the same blocks in MFMA A-operand order for the column-block kernels (scp_qp_pack_operands):
   // [row tile][k step][lane] = A[16 tile + (lane & 15)][4 step + (lane >> 4)], zero beyond the matrix, so that one
@@ -96,6 +97,7 @@ struct scp_qp {
 constexpr int SCP_RESID_STRIDE = 12;  // doubles per workgroup in the partial results of a fused termination check
 constexpr int SCP_RESID_CAP = (4096 / 2 + 128) * SCP_RESID_STRIDE;  // (SCP_PART_CAP / 2 column blocks + row blocks)
 constexpr int SCP_INV_LDS_MAX_K = 96;  // [H_f | I] (K x 2K doubles) resident in LDS for the Gauss-Jordan inverse
+constexpr int SCP_BIGK_MAX_K = 1024;  // single-step pipeline with one workgroup per column and one thread per time step
 constexpr int SCP_FUSED_MAX_K = 120;  // (6K + 4K-1) * 128 B of LDS tiles <= 160 KiB (limit raised above 64 KiB)
 constexpr int SCP_PART_CAP = 4096;  // capacity of each partial-sum array (column blocks of the fused path)
 int scp_qp_fused_iteration(scp_qp* qp, int* cg_count);

@@ -254,12 +254,13 @@ def test_edge_sizes(n, T, h, dim):
     assert rep["collision_free"] and rep["final_position_error"] < 3e-2
 
 
-@pytest.mark.parametrize("T,K", [(12.9, 64), (13.1, 65), (14.0, 70), (24.1, 120), (26.0, 130)])
+@pytest.mark.parametrize("T,K", [(12.9, 64), (13.1, 65), (14.0, 70), (24.1, 120), (26.0, 130), (50.1, 250), (100.1, 500)])
 def test_large_K_paths(T, K):
-    """K = 64 / 65: one / two time steps per lane in the wave scans of the column kernels (and 4 / 8 slab rows per
-    thread in the QP#0 kernel); K = 70, 120: more than 64 KiB of LDS tiles, 120 the largest fused size; K = 130 > 120:
-    the generic one-product-per-launch path (the reference's compute-trajectories demo runs K = 500).  Same oracle,
-    same tolerance."""
+    """K = 64: the persistent kernel's limit (one time step per lane); K = 65: two time steps per lane in the wave scans of
+    the three-launch column kernels (and 8 slab rows per thread in the QP#0 kernel); K = 70, 120: more than 64 KiB of LDS
+    tiles, 120 the largest fused size; K = 130, 250, 500: the long-horizon column kernel (one workgroup per column, block
+    scans; the reference's compute-trajectories demo runs K = 500) with the generic QP#0 and check.  Same oracle, same
+    tolerance."""
     from path_planning.scenarios.position_generator import generate_positions
 
     p0, pf = generate_positions(5, 0.8, seed=2)

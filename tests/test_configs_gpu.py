@@ -118,3 +118,27 @@ def test_scp_128_agents_vs_c_oracle(cg, tol):
         assert all(abs(a - b) <= 50 for a, b in zip(gi, ci)), (gi, ci)
     np.testing.assert_allclose(traj["positions"], ref["positions"], rtol=0, atol=tol)
     np.testing.assert_allclose([q["rel_step"] for q in s.last_info["iterations"]], ref["rel_steps"], rtol=0.05, atol=2e-3)
+
+
+def test_config3_full_solve_vs_c_oracle():
+    """BASELINE config 3 end to end: the complete 1024 x 50 solve (QP#0 + every SCP iteration, default settings: one PCG
+    step, persistent kernel, native loop) against the C oracle's complete solve of the same scenario (~15 s on one host
+    core).  The same ADMM counts per QP and waypoints to 1e-6: at this size the single-step path does not separate from
+    the oracle (bench.py reports 3.5e-13 on the first step)."""
+    from path_planning.scenarios.position_generator import generate_grid_swap
+    from path_planning.solvers.scp import SCP
+
+    N, K = 1024, 50
+    p0, pf, space = generate_grid_swap(N, seed=1000 * N)
+    s = SCP(N, K * 0.2 + 1e-9, 0.2, 0.8, space, verbose=False)
+    s.set_initial_states(p0)
+    s.set_final_states(pf)
+    traj = s.generate_trajectories(15)
+    prob = so.make_problem(N, K * 0.2 + 1e-9, 0.2, 0.8, space, p0, pf)
+    ref = co.scp_solve(prob, 15, qo.Settings(max_iter=10000))
+    assert s.last_info["n_iterations"] == ref["iterations"] and s.last_info["converged"] == ref["converged"]
+    gi = [s.last_info["qp0"]["iter"]] + [q["iter"] for q in s.last_info["iterations"]]
+    assert gi == [q["iter"] for q in ref["infos"]], (gi, [q["iter"] for q in ref["infos"]])
+    assert [q["working_rows"] for q in s.last_info["iterations"]] == [q["working_rows"] for q in ref["infos"][1:]]
+    np.testing.assert_allclose(traj["positions"], ref["positions"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose([q["rel_step"] for q in s.last_info["iterations"]], ref["rel_steps"], rtol=1e-6)

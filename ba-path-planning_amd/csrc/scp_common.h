@@ -9,6 +9,12 @@
 
 #include "scp_hip.h"
 
+// mapped host copy of the stats of the latest pass that produced a row list (written by its last kernel, seq last)
+struct scp_stats_mirror {
+  scp_pair_stats stats;
+  volatile unsigned long long seq;
+};
+
 struct scp_ctx {
   int device;
   int n_cu;  // compute units of the device (resident-workgroup limit of the persistent kernels)
@@ -17,6 +23,7 @@ struct scp_ctx {
   // small device scratch for reductions / host read-back
   double* d_scratch;      // 64 doubles
   double* h_scratch;      // pinned, 64 doubles
+  double* h_scratch_dev;  // its device address (kernels that hand a few numbers to the host write there directly)
   hipEvent_t ev0, ev1;
   hipEvent_t pair_ev0, pair_ev1;  // bracket the most recent pairwise kernel (scp_ctx_last_pair_ms)
   bool pair_timed;
@@ -26,6 +33,9 @@ struct scp_ctx {
   size_t cmp_map_bytes;
   uint32_t* cmp_tot;      // per-block totals / offsets of the bitmap compaction
   size_t cmp_tot_bytes;
+  scp_stats_mirror* h_mirror;  // mapped host memory and its device address
+  scp_stats_mirror* d_mirror;
+  unsigned long long mirror_seq;  // sequence number of the latest compaction launch
 };
 
 static inline int scp_fail(scp_ctx* ctx, int code, const char* fmt, ...) {
@@ -64,6 +74,14 @@ hipError_t scp_raise_lds_limit(int device, const void* kernel, size_t bytes);
 // ~20 us, then poll every ~20 us from a sleep, for many solver threads on few cores (compute-trajectories-batch).
 // Returns false after `timeout_s` seconds.
 bool scp_wait_host_word(volatile unsigned long long* word, unsigned long long seq, int timeout_s);
+
+// Stats of the latest scp_linearize_pairs / scp_collision_violations[_at] call of this ctx, from the host mirror: waits for
+// that pass's last kernel only (no stream drain, no copy launch).
+int scp_ctx_wait_stats(scp_ctx* ctx, scp_pair_stats* out);
+
+// scp_gather_rows + scp_qp_add_rows in one launch: eta / l_col are the outputs of scp_linearize_pairs over [q_begin, q_end)
+int scp_qp_add_rows_from_pass(scp_qp* qp, int64_t n, const int64_t* rows, const double* eta, const double* l_col,
+                              int64_t q_begin, int64_t q_end);
 
 // ---- internal launchers (time-major device layout [K][C], C = N*D) --------------------------------
 // Y[R][C] = alpha * A[R][M] X[M][C] + beta * Y   (row-major; A small and L2 resident)

@@ -30,6 +30,9 @@ extern "C" int scp_ctx_create(int device, void* hip_stream, scp_ctx** out) {
   if (hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ctx->n_cu = 0;
   if (hipMalloc(&ctx->d_scratch, 64 * sizeof(double)) != hipSuccess ||
       hipHostMalloc(&ctx->h_scratch, 64 * sizeof(double)) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&ctx->h_scratch_dev, ctx->h_scratch, 0) != hipSuccess ||
+      hipHostMalloc(&ctx->h_mirror, sizeof(scp_stats_mirror)) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&ctx->d_mirror, ctx->h_mirror, 0) != hipSuccess ||
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
       hipEventCreate(&ctx->pair_ev0) != hipSuccess || hipEventCreate(&ctx->pair_ev1) != hipSuccess) {
     delete ctx;
@@ -48,6 +51,7 @@ extern "C" void scp_ctx_destroy(scp_ctx* ctx) {
   if (ctx->cmp_tot) (void)hipFree(ctx->cmp_tot);
   if (ctx->tm_scratch) (void)hipFree(ctx->tm_scratch);
   (void)hipHostFree(ctx->h_scratch);
+  (void)hipHostFree(ctx->h_mirror);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
   (void)hipEventDestroy(ctx->pair_ev0);
@@ -90,6 +94,16 @@ bool scp_wait_host_word(volatile unsigned long long* word, unsigned long long se
   const bool ok = *word == seq;
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   return ok;
+}
+
+int scp_ctx_wait_stats(scp_ctx* ctx, scp_pair_stats* out) {
+  if (ctx->mirror_seq == 0) return scp_fail(ctx, SCP_ERR_STATE, "no pass with a row list has run yet");
+  if (!scp_wait_host_word(&ctx->h_mirror->seq, ctx->mirror_seq, 30)) {
+    SCP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // surfaces a launch failure, if that is why nothing arrived
+    if (ctx->h_mirror->seq != ctx->mirror_seq) return scp_fail(ctx, SCP_ERR_HIP, "pair pass: the stats mirror was not written");
+  }
+  *out = ctx->h_mirror->stats;
+  return SCP_OK;
 }
 
 extern "C" const char* scp_last_error(const scp_ctx* ctx) { return ctx ? ctx->err : "null context"; }
@@ -335,7 +349,8 @@ __device__ inline void decode_pair(int64_t q, int N, int& i, int& j) {
   j = (int)(q - tri_off(ii, N) + ii + 1);
 }
 
-__global__ void pair_stats_init_kernel(scp_pair_stats* s) {
+// (called by thread 0 of the prep kernel that precedes every pairwise pass: one launch less per pass)
+__device__ inline void pair_stats_init(scp_pair_stats* s) {
   s->min_dist = __longlong_as_double(0x7FF0000000000000LL);
   s->first_violation = 0xFFFFFFFFFFFFFFFFULL;
   s->n_selected = 0;
@@ -428,13 +443,17 @@ struct PairArgs {
   int ablate;            // developer switch (profiling build, env SCP_PAIR_ABLATE): 1 = skip the streaming stores, 2 = force no-LDS
 };
 
-// [N][K][D] -> time-major P and Q = P - (p0 + (k h) v0) (either output may be NULL)
+// [N][K][D] -> time-major P and Q = P - (p0 + (k h) v0) (either output may be NULL); also clears the bitmap the pass
+// is about to mark (linearize), so that no memset launch is needed
 __global__ __launch_bounds__(256) void pair_prep_kernel(int N, int K, int D, double h, const double* __restrict__ pos,
                                                          const double* __restrict__ p0,
                                                          const double* __restrict__ v0, double* __restrict__ P_tm,
-                                                         double* __restrict__ Q_tm) {
+                                                         double* __restrict__ Q_tm, scp_pair_stats* __restrict__ stats,
+                                                         uint32_t* __restrict__ clear_map, int64_t clear_words) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;  // destination index (coalesced writes)
   const int64_t C = (int64_t)N * D;
+  if (t == 0) pair_stats_init(stats);
+  for (int64_t w = t; w < clear_words; w += (int64_t)gridDim.x * 256) clear_map[w] = 0u;
   if (t >= C * K) return;
   const int k = (int)(t / C);
   const int c = (int)(t % C);
@@ -800,9 +819,11 @@ static int ensure_tm(scp_ctx* ctx, size_t bytes) {
 // [N][K][D] -> time-major P_prev and dP = P_new - P_prev (MODE_VIOL_RECOMPUTE)
 __global__ __launch_bounds__(256) void pair_prep_delta_kernel(int N, int K, int D, const double* __restrict__ pos_prev,
                                                                const double* __restrict__ pos_new,
-                                                               double* __restrict__ P_tm, double* __restrict__ dP_tm) {
+                                                               double* __restrict__ P_tm, double* __restrict__ dP_tm,
+                                                               scp_pair_stats* __restrict__ stats) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t C = (int64_t)N * D;
+  if (t == 0) pair_stats_init(stats);
   if (t >= C * K) return;
   const int k = (int)(t / C);
   const int c = (int)(t % C);
@@ -816,7 +837,7 @@ __global__ __launch_bounds__(256) void pair_prep_delta_kernel(int N, int K, int 
 // MODE_VIOL_RECOMPUTE: pos_ref_layout = the linearisation point, p0 = the new positions (v0 unused)
 template <int MODE>
 static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_layout, const double* p0,
-                            const double* v0) {
+                            const double* v0, uint32_t* clear_map = nullptr, int64_t clear_words = 0) {
   const int N = a.N, K = a.K, D = a.D;
   const int64_t nq = a.q_end - a.q_begin;
   const size_t slice = ((size_t)N * K * D + 1) & ~(size_t)1;  // keep the second array 16-byte aligned
@@ -826,13 +847,12 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
   double* Q_tm = MODE != MODE_CHECK ? ctx->tm_scratch + slice : nullptr;
   if (MODE == MODE_VIOL_RECOMPUTE)
     hipLaunchKernelGGL(pair_prep_delta_kernel, dim3(scp_cdiv((int64_t)N * K * D, 256)), dim3(256), 0, ctx->stream, N, K, D,
-                       pos_ref_layout, p0, P_tm, Q_tm);
+                       pos_ref_layout, p0, P_tm, Q_tm, a.stats);
   else
     hipLaunchKernelGGL(pair_prep_kernel, dim3(scp_cdiv((int64_t)N * K * D, 256)), dim3(256), 0, ctx->stream, N, K, D,
-                       a.h, pos_ref_layout, p0, v0, P_tm, Q_tm);
+                       a.h, pos_ref_layout, p0, v0, P_tm, Q_tm, a.stats, clear_map, clear_words);
   a.P_tm = P_tm;
   a.Q_tm = Q_tm;
-  hipLaunchKernelGGL(pair_stats_init_kernel, dim3(1), dim3(1), 0, ctx->stream, a.stats);
   if (nq <= 0) return SCP_OK;
   const size_t lds_bytes = (size_t)((MODE == MODE_LINEARIZE || MODE == MODE_VIOL_RECOMPUTE) ? 2 : 1) * N * D * sizeof(double);
   // the k-slice must start 16-byte aligned in global memory for the double2 staging loads: N*D even
@@ -914,9 +934,29 @@ __global__ __launch_bounds__(CMP_THREADS) void compact_count_kernel(const uint32
   if (threadIdx.x == 0) block_tot[blockIdx.x] = (uint32_t)tot;
 }
 
+// The finished stats of a pass with a row list also go to the ctx's mapped host mirror (sequence number last): the
+// native SCP loop reads them from there without a copy launch and without draining the stream.
+__device__ inline void publish_stats(const scp_pair_stats* stats, unsigned long long n_selected, scp_stats_mirror* mirror,
+                                     unsigned long long seq) {
+  if (!mirror) return;
+  const double mind = __hip_atomic_load(&stats->min_dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const double maxv = __hip_atomic_load(&stats->max_violation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long fv =
+      __hip_atomic_load((const unsigned long long*)&stats->first_violation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((unsigned long long*)&mirror->stats.min_dist, (unsigned long long)__double_as_longlong(mind),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store((unsigned long long*)&mirror->stats.first_violation, fv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store((unsigned long long*)&mirror->stats.n_selected, n_selected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store((unsigned long long*)&mirror->stats.max_violation, (unsigned long long)__double_as_longlong(maxv),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store((unsigned long long*)&mirror->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // exclusive scan of the block totals in place (one workgroup; nblocks is a few hundred), total -> stats
 __global__ __launch_bounds__(CMP_THREADS) void compact_scan_kernel(uint32_t* __restrict__ block_tot, int nblocks,
-                                                                    scp_pair_stats* __restrict__ stats) {
+                                                                    scp_pair_stats* __restrict__ stats,
+                                                                    scp_stats_mirror* __restrict__ mirror,
+                                                                    unsigned long long seq) {
   int carry = 0;
   for (int b0 = 0; b0 < nblocks; b0 += CMP_THREADS) {
     const int b = b0 + threadIdx.x;
@@ -926,7 +966,10 @@ __global__ __launch_bounds__(CMP_THREADS) void compact_scan_kernel(uint32_t* __r
     if (b < nblocks) block_tot[b] = (uint32_t)(carry + ex);
     carry += tot;
   }
-  if (threadIdx.x == 0) stats->n_selected = (unsigned long long)carry;
+  if (threadIdx.x == 0) {
+    stats->n_selected = (unsigned long long)carry;
+    publish_stats(stats, (unsigned long long)carry, mirror, seq);
+  }
 }
 
 // write the global row id of every set bit; optionally merge the map into `merge_into` and clear it.  When the list
@@ -967,6 +1010,88 @@ __global__ __launch_bounds__(CMP_THREADS) void compact_write_kernel(uint32_t* __
   }
 }
 
+// Small maps (up to CMP1_MAX_WORDS words = 2 M rows, e.g. every map of a 128-agent problem): count, scan, write and the
+// stats mirror in ONE workgroup -- the three-launch version costs more in launch boundaries than in work there.
+constexpr int CMP1_THREADS = 1024;
+constexpr int CMP1_WORDS = CMP1_THREADS * CMP_WPT;
+constexpr int64_t CMP1_MAX_WORDS = 64 * 1024;
+
+__global__ __launch_bounds__(CMP1_THREADS) void compact_small_kernel(uint32_t* __restrict__ map, int64_t words, int64_t nq,
+                                                                      int64_t q_begin, int64_t pairs,
+                                                                      int64_t* __restrict__ rows, int64_t cap,
+                                                                      uint32_t* __restrict__ merge_into,
+                                                                      scp_pair_stats* __restrict__ stats,
+                                                                      scp_stats_mirror* __restrict__ mirror,
+                                                                      unsigned long long seq) {
+  __shared__ int wsum[CMP1_THREADS / 64];
+  __shared__ int total_sh;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // pass 1: the total (decides whether a merging pass may merge at all)
+  int c_all = 0;
+  for (int64_t w = threadIdx.x; w < words; w += CMP1_THREADS) c_all += __popc(map[w]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c_all += __shfl_xor(c_all, o);
+  if (lane == 0) wsum[wave] = c_all;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < CMP1_THREADS / 64; ++w) t += wsum[w];
+    total_sh = t;
+  }
+  __syncthreads();
+  const int total = total_sh;
+  const bool overflow = merge_into != nullptr && (int64_t)total > cap;
+  // pass 2: chunk by chunk in row order, block scan per chunk
+  int64_t carry = 0;
+  for (int64_t base = 0; base < words && total > 0; base += CMP1_WORDS) {
+    const int64_t w0 = base + (int64_t)threadIdx.x * CMP_WPT;
+    uint32_t wd[CMP_WPT];
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < CMP_WPT; ++i) {
+      wd[i] = (w0 + i < words) ? map[w0 + i] : 0u;
+      c += __popc(wd[i]);
+    }
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    __syncthreads();  // wsum of the previous chunk (or of pass 1) has been read by everyone
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < CMP1_THREADS / 64; ++w) {
+      if (w < wave) before += wsum[w];
+      tot += wsum[w];
+    }
+    int64_t slot = carry + before + incl - c;
+    carry += tot;
+    if (c == 0) continue;
+#pragma unroll
+    for (int i = 0; i < CMP_WPT; ++i) {
+      uint32_t m = wd[i];
+      if (m && merge_into) {
+        if (!overflow) merge_into[w0 + i] |= m;
+        map[w0 + i] = 0u;
+      }
+      while (m) {
+        const int bit = __ffs((int)m) - 1;
+        m &= m - 1;
+        const int64_t lr = (w0 + i) * 32 + bit;
+        if (!overflow && slot < cap) rows[slot] = (lr / nq) * pairs + q_begin + (lr % nq);
+        ++slot;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    stats->n_selected = (unsigned long long)total;
+    publish_stats(stats, (unsigned long long)total, mirror, seq);
+  }
+}
+
 static int ensure_cmp(scp_ctx* ctx, int64_t words) {
   const size_t need_map = (size_t)words * sizeof(uint32_t);
   const size_t need_tot = (size_t)(scp_cdiv(words, CMP_WORDS) + 1) * sizeof(uint32_t);
@@ -997,9 +1122,17 @@ static int ensure_cmp(scp_ctx* ctx, int64_t words) {
 static int launch_compaction(scp_ctx* ctx, uint32_t* map, int64_t words, int64_t nq, int64_t q_begin, int64_t pairs,
                              int64_t* rows, int64_t cap, uint32_t* merge_into, scp_pair_stats* stats) {
   if (words <= 0) return SCP_OK;
+  const unsigned long long seq = ++ctx->mirror_seq;
+  if (words <= CMP1_MAX_WORDS) {
+    hipLaunchKernelGGL(compact_small_kernel, dim3(1), dim3(CMP1_THREADS), 0, ctx->stream, map, words, nq, q_begin, pairs,
+                       rows, cap, merge_into, stats, ctx->d_mirror, seq);
+    SCP_HIP_CHECK(ctx, hipGetLastError());
+    return SCP_OK;
+  }
   const int nblocks = scp_cdiv(words, CMP_WORDS);
   hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(CMP_THREADS), 0, ctx->stream, map, words, ctx->cmp_tot);
-  hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(CMP_THREADS), 0, ctx->stream, ctx->cmp_tot, nblocks, stats);
+  hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(CMP_THREADS), 0, ctx->stream, ctx->cmp_tot, nblocks, stats,
+                     ctx->d_mirror, seq);
   hipLaunchKernelGGL(compact_write_kernel, dim3(nblocks), dim3(CMP_THREADS), 0, ctx->stream, map, words, ctx->cmp_tot,
                      nq, q_begin, pairs, rows, cap, merge_into, stats);
   SCP_HIP_CHECK(ctx, hipGetLastError());
@@ -1039,8 +1172,7 @@ extern "C" int scp_linearize_pairs(scp_ctx* ctx, int N, int K, int D, double R, 
   const int64_t words = (K * nq + 31) / 32;
   rc = ensure_cmp(ctx, words);
   if (rc) return rc;
-  if (words) SCP_HIP_CHECK(ctx, hipMemsetAsync(sel_bitmap, 0, (size_t)words * sizeof(uint32_t), ctx->stream));
-  rc = launch_pair_pass<MODE_LINEARIZE>(ctx, a, pos_prev, p0, v0);
+  rc = launch_pair_pass<MODE_LINEARIZE>(ctx, a, pos_prev, p0, v0, sel_bitmap, words);  // (its prep kernel clears the map)
   if (rc) return rc;
   return launch_compaction(ctx, sel_bitmap, words, nq, q_begin, a.pairs, sel_rows, sel_cap, nullptr, stats);
 }
@@ -1172,11 +1304,10 @@ extern "C" int scp_rel_step(scp_ctx* ctx, int64_t n, const double* a_new, const 
   if (!ctx) return SCP_ERR_INVALID;
   SCP_REQUIRE(ctx, n > 0 && a_new && a_prev && out, "rel_step: bad arguments");
   const int blocks = (int)((n + 256 * 8 - 1) / (256 * 8)) < 32 ? (int)((n + 256 * 8 - 1) / (256 * 8)) : 32;
+  // the (at most 64) partial sums go straight to the mapped host scratch: no copy launch
   hipLaunchKernelGGL(rel_step_partial_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, a_new, a_prev,
-                     ctx->d_scratch);
+                     ctx->h_scratch_dev);
   SCP_HIP_CHECK(ctx, hipGetLastError());
-  SCP_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_scratch, ctx->d_scratch, 2 * blocks * sizeof(double),
-                                    hipMemcpyDeviceToHost, ctx->stream));
   SCP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   double d2 = 0.0, b2 = 0.0;
   for (int b = 0; b < blocks; ++b) {

@@ -402,10 +402,13 @@ __global__ __launch_bounds__(256) void gj_finish_kernel(int K, const double* __r
 }
 
 // append working rows: decode (k, i, j), copy eta / l, z = max(A x, l), y = 0
+// eta_stride == 0: eta_in / l_in are the gathered [n][D] / [n] arrays of scp_gather_rows; otherwise they are the arrays of
+// the pairwise pass itself (pair range [q_begin, q_begin + nq)) and the gather happens here.
 __global__ __launch_bounds__(256) void add_rows_kernel(int N, int D, int64_t C, int64_t pairs, int64_t base, int64_t n,
                                                         const int64_t* __restrict__ rows,
                                                         const double* __restrict__ eta_in,
-                                                        const double* __restrict__ l_in, const double* __restrict__ Q,
+                                                        const double* __restrict__ l_in, int64_t eta_stride,
+                                                        int64_t q_begin, int64_t nq, const double* __restrict__ Q,
                                                         int64_t* __restrict__ w_row, int* __restrict__ wk,
                                                         int* __restrict__ wi, int* __restrict__ wj,
                                                         double* __restrict__ weta, double* __restrict__ wl,
@@ -427,16 +430,54 @@ __global__ __launch_bounds__(256) void add_rows_kernel(int N, int D, int64_t C, 
   wk[o] = (int)k;
   wi[o] = (int)ii;
   wj[o] = (int)jj;
+  const int64_t lr = k * nq + (q - q_begin);
   double ax = 0.0;
   for (int d = 0; d < D; ++d) {
-    const double e = eta_in[t * D + d];
+    const double e = eta_stride ? eta_in[(int64_t)d * eta_stride + lr] : eta_in[t * D + d];
     weta[o * D + d] = e;
     ax += e * (Q[k * C + ii * D + d] - Q[k * C + jj * D + d]);
   }
-  const double lo = l_in[t];
+  const double lo = eta_stride ? l_in[lr] : l_in[t];
   wl[o] = lo;
   zc[o] = fmax(ax, lo);
   yc[o] = 0.0;
+}
+
+// scp_qp_reset in one launch (K <= SCP_FUSED_MAX_K): x0 in reference order [N][K][D] (null: zeros) -> x (time-major),
+// z_f = F x, the carried F x and S0 x of the single-step pipeline (exact), y_f = 0.  64 columns per workgroup, the x tile in
+// LDS, every wave takes a quarter of the rows (row coefficients are wave-uniform: scalar loads).
+constexpr int RESET_COLS = 64;
+__global__ __launch_bounds__(256) void qp_reset_kernel(int N, int K, int D, int Rf, const double* __restrict__ x0,
+                                                        const double* __restrict__ F, const double* __restrict__ S0,
+                                                        double* __restrict__ x, double* __restrict__ zf,
+                                                        double* __restrict__ fx, double* __restrict__ Qx,
+                                                        double* __restrict__ yf) {
+  extern __shared__ double reset_xs[];  // [K][RESET_COLS]
+  const int64_t C = (int64_t)N * D;
+  const int lc = threadIdx.x & (RESET_COLS - 1), rg = threadIdx.x / RESET_COLS;
+  const int64_t c = (int64_t)blockIdx.x * RESET_COLS + lc;
+  const bool live = c < C;
+  const int64_t agent = live ? c / D : 0;
+  const int dim = live ? (int)(c - agent * D) : 0;
+  for (int k = rg; k < K; k += 256 / RESET_COLS) {
+    const double v = (live && x0) ? x0[(agent * K + k) * D + dim] : 0.0;
+    reset_xs[k * RESET_COLS + lc] = v;
+    if (live) x[(int64_t)k * C + c] = v;
+  }
+  __syncthreads();
+  for (int r = rg; r < Rf + K; r += 256 / RESET_COLS) {
+    const double* __restrict__ row = r < Rf ? F + (size_t)r * K : S0 + (size_t)(r - Rf) * K;
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) acc += row[k] * reset_xs[k * RESET_COLS + lc];
+    if (!live) continue;
+    if (r < Rf) {
+      zf[(int64_t)r * C + c] = acc;
+      fx[(int64_t)r * C + c] = acc;
+      yf[(int64_t)r * C + c] = 0.0;
+    } else {
+      Qx[(int64_t)(r - Rf) * C + c] = acc;
+    }
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -918,42 +959,74 @@ extern "C" int scp_qp_reset(scp_qp* qp, const double* x0) {
   if (!qp->problem_set) return scp_fail(ctx, SCP_ERR_STATE, "qp_reset: call scp_qp_set_problem first");
   const QpDev& d = qp->d;
   const int64_t nx = (int64_t)qp->K * qp->C, nf = (int64_t)qp->Rf * qp->C;
-  if (x0) QP_CHECK(scp_launch_to_time_major(ctx, qp->N, qp->K, qp->D, x0, d.x));
-  else SCP_HIP_CHECK(ctx, hipMemsetAsync(d.x, 0, nx * sizeof(double), ctx->stream));
-  QP_CHECK(gemm(qp, qp->Rf, qp->K, 1.0, d.F, d.x, 0.0, d.zf));  // z = A x  (primal warm start, scp.py:443)
-  SCP_HIP_CHECK(ctx, hipMemsetAsync(d.yf, 0, nf * sizeof(double), ctx->stream));
+  const bool one_launch = qp->st.use_mfma == 1 && qp->K <= SCP_FUSED_MAX_K;
+  if (one_launch) {
+    // z = A x (primal warm start, scp.py:443), y = 0 and the single-step pipeline's carried F x, S0 x in one launch
+    hipLaunchKernelGGL(qp_reset_kernel, dim3(scp_cdiv(qp->C, RESET_COLS)), dim3(256),
+                       (size_t)qp->K * RESET_COLS * sizeof(double), ctx->stream, qp->N, qp->K, qp->D, qp->Rf, x0, d.F, d.S0,
+                       d.x, d.zf, d.fx, d.HQ + nx, d.yf);
+    QP_LAUNCHED(qp);
+    qp->qx_sel = 0;
+  } else {
+    if (x0) QP_CHECK(scp_launch_to_time_major(ctx, qp->N, qp->K, qp->D, x0, d.x));
+    else SCP_HIP_CHECK(ctx, hipMemsetAsync(d.x, 0, nx * sizeof(double), ctx->stream));
+    QP_CHECK(gemm(qp, qp->Rf, qp->K, 1.0, d.F, d.x, 0.0, d.zf));  // z = A x  (primal warm start, scp.py:443)
+    SCP_HIP_CHECK(ctx, hipMemsetAsync(d.yf, 0, nf * sizeof(double), ctx->stream));
+  }
   qp->nW = 0;
   qp->persist_cap_nW = -1;
   qp->rho = qp->st.rho;
   qp->cg1_ready = false;
   qp->csr_valid = false;
-  qp->qx_fresh = false;
+  qp->qx_fresh = one_launch;  // F x and S0 x of this x are in place
   QP_CHECK(build_kkt(qp));
   qp->reset_done = true;
   return SCP_OK;
 }
 
-extern "C" int scp_qp_add_rows(scp_qp* qp, int64_t n, const int64_t* rows, const double* w_eta, const double* w_l) {
-  if (!qp) return SCP_ERR_INVALID;
+// eta_stride == 0: gathered rows (the public entry point); > 0: eta / l are the arrays of the pairwise pass over the pair
+// range [q_begin, q_begin + nq), gathered by the kernel
+static int add_rows_impl(scp_qp* qp, int64_t n, const int64_t* rows, const double* eta, const double* l, int64_t eta_stride,
+                         int64_t q_begin, int64_t nq) {
   scp_ctx* ctx = qp->ctx;
   if (!qp->reset_done) return scp_fail(ctx, SCP_ERR_STATE, "qp_add_rows: call scp_qp_reset first");
   if (n <= 0) return SCP_OK;
-  SCP_REQUIRE(ctx, rows && w_eta && w_l, "qp_add_rows: null pointer");
+  SCP_REQUIRE(ctx, rows && eta && l, "qp_add_rows: null pointer");
   if (qp->nW + n > qp->row_cap)
     return scp_fail(ctx, SCP_ERR_CAPACITY, "qp_add_rows: %lld + %lld rows exceed the capacity %lld",
                     (long long)qp->nW, (long long)n, (long long)qp->row_cap);
   const QpDev& d = qp->d;
   const int64_t nx = (int64_t)qp->K * qp->C;
-  QP_CHECK(gemm(qp, qp->K, qp->K, 1.0, d.S0, d.x, 0.0, d.HQ + nx));
+  // S0 x for z_c = max(A_c x, l): the single-step pipeline's exact copy when there is one (after a reset, after a solve's
+  // last check), else computed into the spare slab
+  const double* Qx = qp->qx_sel ? d.HQ : d.HQ + nx;
+  if (!qp->qx_fresh) {
+    QP_CHECK(gemm(qp, qp->K, qp->K, 1.0, d.S0, d.x, 0.0, d.HQ + nx));  // (HQ is scratch whenever qx_fresh is false)
+    Qx = d.HQ + nx;
+  }
   hipLaunchKernelGGL(add_rows_kernel, grid1(n), dim3(256), 0, ctx->stream, qp->N, qp->D, qp->C, scp_pairs(qp->N),
-                     qp->nW, n, rows, w_eta, w_l, d.HQ + nx, d.w_row, d.w_k, d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc);
+                     qp->nW, n, rows, eta, l, eta_stride, q_begin, nq, Qx, d.w_row, d.w_k, d.w_i, d.w_j, d.w_eta, d.w_l, d.zc,
+                     d.yc);
   QP_LAUNCHED(qp);
   qp->nW += n;
   qp->persist_cap_nW = -1;
   qp->cg1_ready = false;
   qp->csr_valid = false;
-  qp->qx_fresh = false;  // HQ was scratch
   return SCP_OK;
+}
+
+extern "C" int scp_qp_add_rows(scp_qp* qp, int64_t n, const int64_t* rows, const double* w_eta, const double* w_l) {
+  if (!qp) return SCP_ERR_INVALID;
+  return add_rows_impl(qp, n, rows, w_eta, w_l, 0, 0, 1);
+}
+
+// scp_gather_rows + scp_qp_add_rows in one launch (used by the native SCP loop): eta / l_col are the outputs of
+// scp_linearize_pairs over the pair range [q_begin, q_end)
+int scp_qp_add_rows_from_pass(scp_qp* qp, int64_t n, const int64_t* rows, const double* eta, const double* l_col,
+                              int64_t q_begin, int64_t q_end) {
+  if (!qp) return SCP_ERR_INVALID;
+  SCP_REQUIRE(qp->ctx, q_begin >= 0 && q_end > q_begin && q_end <= scp_pairs(qp->N), "qp_add_rows_from_pass: bad pair range");
+  return add_rows_impl(qp, n, rows, eta, l_col, scp_eta_stride(qp->K, q_end - q_begin), q_begin, q_end - q_begin);
 }
 
 extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {

@@ -1234,6 +1234,16 @@ int scp_qp_qp0_iterations(scp_qp* qp, int nit, double* dy_out) {
   return SCP_OK;
 }
 
+namespace {
+constexpr int CSR1_MAX_CELLS = 16384;
+constexpr int64_t CSR1_MAX_ROWS = 1 << 18;
+__global__ void csr_small_kernel(int64_t nW, int K, int ncell, int D, int64_t C, double rho, const int* __restrict__ wk,
+                                 const int* __restrict__ wi, const int* __restrict__ wj, const double* __restrict__ weta,
+                                 const double* __restrict__ Qx, const double* __restrict__ zc, const double* __restrict__ yc,
+                                 int* __restrict__ ptr, int* __restrict__ ent, double* __restrict__ coef,
+                                 int* __restrict__ pos_i, int* __restrict__ pos_j, double* __restrict__ gval);
+}  // namespace
+
 // Bring the single-step pipeline's carried state in line with (x, zc, yc, rho): S0 x and F x exact, row values g.
 int scp_qp_cg1_prepare(scp_qp* qp) {
   const QpDev& d = qp->d;
@@ -1249,6 +1259,15 @@ int scp_qp_cg1_prepare(scp_qp* qp) {
   }
   qp->qx_fresh = false;
   const double* Qx = qp->qx_sel ? d.HQ : d.HQ + nx;
+  if (!qp->csr_valid && qp->nW > 0 && qp->nW <= CSR1_MAX_ROWS && qp->N * K <= CSR1_MAX_CELLS) {
+    const int ncell = qp->N * K;
+    hipLaunchKernelGGL(csr_small_kernel, dim3(1), dim3(1024), (size_t)ncell * sizeof(int), s, qp->nW, K, ncell, qp->D, C, rho_c,
+                       d.w_k, d.w_i, d.w_j, d.w_eta, Qx, d.zc, d.yc, d.cell_ptr, d.ent_code, d.coef, d.pos_i, d.pos_j, d.gval);
+    FUSED_LAUNCHED(qp);
+    qp->csr_valid = true;
+    qp->cg1_ready = true;
+    return SCP_OK;
+  }
   if (!qp->csr_valid) {
     int rc = scp_qp_csr_build(qp);
     if (rc) return rc;
@@ -1438,6 +1457,93 @@ __global__ __launch_bounds__(256) void csr_finish_kernel(int64_t nent, int D, co
   for (int d = 0; d < D; ++d) coef[t * D + d] = side ? -weta[(int64_t)n * D + d] : weta[(int64_t)n * D + d];
   if (side) pos_j[n] = (int)t;
   else pos_i[n] = (int)t;
+}
+
+// Small problems (N K <= CSR1_MAX_CELLS cells, e.g. 128 agents x 50 steps): the whole build -- count, scan, fill, sort,
+// finish -- and the first row values (cg1_rows_init_kernel) in ONE workgroup; the cell counters live in LDS.  Same lists,
+// same order as the five-launch build.
+__global__ __launch_bounds__(1024) void csr_small_kernel(int64_t nW, int K, int ncell, int D, int64_t C, double rho,
+                                                          const int* __restrict__ wk, const int* __restrict__ wi,
+                                                          const int* __restrict__ wj, const double* __restrict__ weta,
+                                                          const double* __restrict__ Qx, const double* __restrict__ zc,
+                                                          const double* __restrict__ yc, int* __restrict__ ptr,
+                                                          int* __restrict__ ent, double* __restrict__ coef,
+                                                          int* __restrict__ pos_i, int* __restrict__ pos_j,
+                                                          double* __restrict__ gval) {
+  extern __shared__ int csr_cnt[];  // [ncell]: counts, then exclusive offsets, then fill cursors (= end of each cell)
+  __shared__ int wsum[16];
+  constexpr int SC = CSR1_MAX_CELLS / 1024;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < ncell; c += 1024) csr_cnt[c] = 0;
+  __syncthreads();
+  for (int64_t n = tid; n < nW; n += 1024) {
+    atomicAdd(&csr_cnt[cell_of(wk[n], wi[n], K)], 1);
+    atomicAdd(&csr_cnt[cell_of(wk[n], wj[n], K)], 1);
+  }
+  __syncthreads();
+  {  // exclusive scan, SC consecutive cells per thread
+    int v[SC], tot = 0;
+#pragma unroll
+    for (int e = 0; e < SC; ++e) {
+      v[e] = SC * tid + e < ncell ? csr_cnt[SC * tid + e] : 0;
+      tot += v[e];
+    }
+    int incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - tot;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+    for (int e = 0; e < SC; ++e) {
+      if (SC * tid + e < ncell) {
+        csr_cnt[SC * tid + e] = run;
+        ptr[SC * tid + e] = run;
+      }
+      run += v[e];
+    }
+    if (tid == 1023) ptr[ncell] = run;
+  }
+  __syncthreads();
+  for (int64_t n = tid; n < nW; n += 1024) {
+    ent[atomicAdd(&csr_cnt[cell_of(wk[n], wi[n], K)], 1)] = (int)(2 * n);
+    ent[atomicAdd(&csr_cnt[cell_of(wk[n], wj[n], K)], 1)] = (int)(2 * n + 1);
+  }
+  __syncthreads();
+  for (int c = tid; c < ncell; c += 1024) {  // the cursor of a cell now stands at its end = the next cell's begin
+    const int b = c ? csr_cnt[c - 1] : 0, e = csr_cnt[c];
+    for (int i = b + 1; i < e; ++i) {
+      const int v = ent[i];
+      int j = i - 1;
+      while (j >= b && ent[j] > v) {
+        ent[j + 1] = ent[j];
+        --j;
+      }
+      ent[j + 1] = v;
+    }
+  }
+  __syncthreads();
+  for (int64_t t = tid; t < 2 * nW; t += 1024) {
+    const int code = ent[t];
+    const int n = code >> 1, side = code & 1;
+    for (int d = 0; d < D; ++d) coef[t * D + d] = side ? -weta[(int64_t)n * D + d] : weta[(int64_t)n * D + d];
+    if (side) pos_j[n] = (int)t;
+    else pos_i[n] = (int)t;
+  }
+  __syncthreads();
+  for (int64_t n = tid; n < nW; n += 1024) {  // cg1_rows_init_kernel
+    const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
+    const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
+    double ax = 0.0;
+    for (int d = 0; d < D; ++d) ax += weta[n * D + d] * (Qx[bi + d] - Qx[bj + d]);
+    const double g = (rho * zc[n] - yc[n]) - rho * ax;
+    gval[pos_i[n]] = g;
+    gval[pos_j[n]] = g;
+  }
 }
 
 // row values for the residual / certificate scatters
@@ -1839,14 +1945,16 @@ int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
                        has_rows, d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval2, d.gval3, Qx, d.fx, part);
   }
   double* rpart = part + (size_t)nblk * SCP_RESID_STRIDE;
-  if (qp->D == 2)
+  if (!has_rows) {
+    // QP#0: no row partials
+  } else if (qp->D == 2)
     hipLaunchKernelGGL(cg1_resid_rows_kernel<2>, dim3(RESID_ROW_BLOCKS), dim3(256), 0, s, qp->nW, C, with_dy ? 1 : 0, d.w_k,
                        d.w_i, d.w_j, d.w_eta, d.w_l, Qx, d.zc, d.dyc, rpart);
   else
     hipLaunchKernelGGL(cg1_resid_rows_kernel<3>, dim3(RESID_ROW_BLOCKS), dim3(256), 0, s, qp->nW, C, with_dy ? 1 : 0, d.w_k,
                        d.w_i, d.w_j, d.w_eta, d.w_l, Qx, d.zc, d.dyc, rpart);
   FUSED_LAUNCHED(qp);
-  const int npart = nblk + RESID_ROW_BLOCKS;
+  const int npart = nblk + (has_rows ? RESID_ROW_BLOCKS : 0);
   volatile unsigned long long* flag = (volatile unsigned long long*)(qp->h_scal + SL_COUNT + SCP_RESID_CAP);
   const unsigned long long seq = ++qp->check_seq;
   hipLaunchKernelGGL(check_done_kernel, dim3(1), dim3(1), 0, s, (unsigned long long*)(qp->h_scal_dev + SL_COUNT + SCP_RESID_CAP),

@@ -27,7 +27,6 @@ struct scp_solver {
   uint32_t* bitmap;
   int64_t* sel;
   int64_t sel_cap;
-  double *w_eta, *w_l;
   scp_pair_stats* stats;    // device
   scp_pair_stats* h_stats;  // pinned
   // QP
@@ -50,7 +49,10 @@ namespace {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int read_stats(scp_solver* s) {
+// stats of the pass just enqueued.  Passes that end in a row list (linearise, violations) publish them in the ctx's mapped
+// host mirror; the check pass has no trailing kernel, its stats are copied.
+int read_stats(scp_solver* s, bool from_mirror) {
+  if (from_mirror && s->pairs > 0) return scp_ctx_wait_stats(s->ctx, s->h_stats);
   SV_HIP(hipMemcpyAsync(s->h_stats, s->stats, sizeof(scp_pair_stats), hipMemcpyDeviceToHost, s->ctx->stream));
   SV_HIP(hipStreamSynchronize(s->ctx->stream));
   return SCP_OK;
@@ -61,12 +63,8 @@ int grow_sel(scp_solver* s, int64_t need) {
   cap = std::min<int64_t>(std::max<int64_t>(s->rows, 1), cap);
   SV_HIP(hipStreamSynchronize(s->ctx->stream));
   SV_HIP(hipFree(s->sel));
-  SV_HIP(hipFree(s->w_eta));
-  SV_HIP(hipFree(s->w_l));
-  s->sel = nullptr; s->w_eta = nullptr; s->w_l = nullptr;
+  s->sel = nullptr;
   SV_HIP(hipMalloc(&s->sel, (size_t)cap * sizeof(int64_t)));
-  SV_HIP(hipMalloc(&s->w_eta, (size_t)cap * s->D * sizeof(double)));
-  SV_HIP(hipMalloc(&s->w_l, (size_t)cap * sizeof(double)));
   s->sel_cap = cap;
   return SCP_OK;
 }
@@ -112,15 +110,16 @@ int grow_qp(scp_solver* s, int64_t need, bool keep_state, const double* limits, 
 int add_rows_growing(scp_solver* s, int64_t n, int64_t have, bool keep_state, const double* x0, const double* limits,
                      const double* space, const double* p0, const double* v0, const double* pf, const double* vf) {
   if (n <= 0) return SCP_OK;
-  int rc = scp_qp_add_rows(s->qp, n, s->sel, s->w_eta, s->w_l);
+  int rc = scp_qp_add_rows_from_pass(s->qp, n, s->sel, s->eta, s->l, 0, s->pairs);  // (gathers the rows itself)
   if (rc != SCP_ERR_CAPACITY) return rc;
   SV_CHECK(grow_qp(s, have + n, keep_state, limits, space, p0, v0, pf, vf));
   if (!keep_state) SV_CHECK(scp_qp_reset(s->qp, x0));
-  return scp_qp_add_rows(s->qp, n, s->sel, s->w_eta, s->w_l);
+  return scp_qp_add_rows_from_pass(s->qp, n, s->sel, s->eta, s->l, 0, s->pairs);
 }
 
-// _solve_with_avoidance_constraints (scp.py:399-451): linearise around `acc_in`, joint QP with exact constraint
-// generation; result in s->x.  eps > 0: termination tolerances of this one QP (the polish step).
+// _solve_with_avoidance_constraints (scp.py:399-451): linearise around `acc_in` (whose positions the caller holds in
+// s->pos_a), joint QP with exact constraint generation; result in s->x, its positions in s->pos_b.  eps > 0: termination
+// tolerances of this one QP (the polish step).
 int solve_joint_qp(scp_solver* s, const double* acc_in, const double* limits, const double* space, const double* p0,
                    const double* v0, const double* pf, const double* vf, const scp_solve_options* o, double eps,
                    scp_qp_record* rec) {
@@ -134,16 +133,14 @@ int solve_joint_qp(scp_solver* s, const double* acc_in, const double* limits, co
     max_iter = std::max(max_iter, 40000);
   }
   double* prev_pos = s->pos_a;
-  SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, acc_in, p0, v0, prev_pos, nullptr));
   for (;;) {
     SV_CHECK(scp_linearize_pairs(ctx, N, K, D, s->R, s->h, 0, s->pairs, prev_pos, p0, v0, s->eta, s->l, o->working_set_margin,
                                  s->sel, s->sel_cap, s->bitmap, s->stats));
-    SV_CHECK(read_stats(s));
+    SV_CHECK(read_stats(s, true));
     if ((int64_t)s->h_stats->n_selected <= s->sel_cap) break;
     SV_CHECK(grow_sel(s, (int64_t)s->h_stats->n_selected));
   }
   int64_t n = (int64_t)s->h_stats->n_selected;
-  if (n > 0) SV_CHECK(scp_gather_rows(ctx, N, K, D, 0, s->pairs, s->eta, s->l, s->sel, n, s->w_eta, s->w_l));
   SV_CHECK(scp_qp_update_settings(s->qp, &s->st));
   SV_CHECK(scp_qp_reset(s->qp, acc_in));
   SV_CHECK(add_rows_growing(s, n, 0, false, acc_in, limits, space, p0, v0, pf, vf));
@@ -152,7 +149,10 @@ int solve_joint_qp(scp_solver* s, const double* acc_in, const double* limits, co
   int used = 0;
   scp_qp_info info{};
   memset(rec, 0, sizeof(*rec));
-  SV_HIP(hipMemcpyAsync(s->x, acc_in, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+  if (o->max_rounds < 1) {  // no round runs: the "solution" is the linearisation point
+    SV_HIP(hipMemcpyAsync(s->x, acc_in, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    SV_HIP(hipMemcpyAsync(s->pos_b, s->pos_a, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+  }
   double max_v = 0.0;
   int rounds = 0;
   for (int rnd = 0; rnd < o->max_rounds; ++rnd) {
@@ -169,7 +169,7 @@ int solve_joint_qp(scp_solver* s, const double* acc_in, const double* limits, co
     for (;;) {
       SV_CHECK(scp_collision_violations_at(ctx, N, K, D, s->R, 0, s->pairs, prev_pos, s->pos_b, o->feasibility_tol, s->sel,
                                            s->sel_cap, s->bitmap, s->stats));
-      SV_CHECK(read_stats(s));
+      SV_CHECK(read_stats(s, true));
       if ((int64_t)s->h_stats->n_selected <= s->sel_cap) break;
       SV_CHECK(grow_sel(s, (int64_t)s->h_stats->n_selected));
     }
@@ -178,7 +178,6 @@ int solve_joint_qp(scp_solver* s, const double* acc_in, const double* limits, co
     if (rounds < SCP_MAX_ROUNDS_RECORDED) rec->added[rounds] = n;
     ++rounds;
     if (n == 0 || used >= max_iter) break;
-    SV_CHECK(scp_gather_rows(ctx, N, K, D, 0, s->pairs, s->eta, s->l, s->sel, n, s->w_eta, s->w_l));
     SV_CHECK(add_rows_growing(s, n, nW, true, nullptr, limits, space, p0, v0, pf, vf));
     nW += n;
   }
@@ -214,7 +213,7 @@ extern "C" void scp_solver_destroy(scp_solver* s) {
   if (!s) return;
   (void)hipStreamSynchronize(s->ctx->stream);
   if (s->qp) scp_qp_destroy(s->qp);
-  void* dev[] = {s->eta, s->l, s->bitmap, s->sel, s->w_eta, s->w_l, s->stats, s->ws, s->acc, s->x, s->pos_a, s->pos_b, s->vel};
+  void* dev[] = {s->eta, s->l, s->bitmap, s->sel, s->stats, s->ws, s->acc, s->x, s->pos_a, s->pos_b, s->vel};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (s->h_stats) (void)hipHostFree(s->h_stats);
@@ -243,8 +242,6 @@ extern "C" int scp_solver_create(scp_ctx* ctx, int N, int K, int D, double h, do
             hipMalloc(&s->l, (size_t)std::max<int64_t>(s->rows + (s->rows & 1), 2) * sizeof(double)) == hipSuccess &&
             hipMalloc(&s->bitmap, (size_t)std::max<int64_t>((s->rows + 31) / 32, 1) * sizeof(uint32_t)) == hipSuccess &&
             hipMalloc(&s->sel, (size_t)s->sel_cap * sizeof(int64_t)) == hipSuccess &&
-            hipMalloc(&s->w_eta, (size_t)s->sel_cap * D * sizeof(double)) == hipSuccess &&
-            hipMalloc(&s->w_l, (size_t)s->sel_cap * sizeof(double)) == hipSuccess &&
             hipMalloc(&s->stats, sizeof(scp_pair_stats)) == hipSuccess &&
             hipHostMalloc(&s->h_stats, sizeof(scp_pair_stats)) == hipSuccess &&
             hipHostMalloc(&s->pair_pts, 2 * 3 * sizeof(double)) == hipSuccess &&
@@ -312,7 +309,7 @@ extern "C" int scp_solver_solve(scp_solver* s, const double* limits, const doubl
   // a4 + a8: initial guess, avoidance check evaluated ONCE (scp.py:140-144, never refreshed inside the loop :152)
   SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, s->acc, p0, v0, s->pos_a, nullptr));
   SV_CHECK(scp_check_avoidance(ctx, N, K, D, s->R, 0, s->pairs, s->pos_a, s->stats));
-  SV_CHECK(read_stats(s));
+  SV_CHECK(read_stats(s, false));
   bool is_feasible = s->h_stats->first_violation == UINT64_MAX;
   res->first_violation = s->h_stats->first_violation;
   if (!is_feasible && s->pairs > 0) {  // distance of the first violating pair, for the reference's print (scp.py:611-613)
@@ -348,12 +345,13 @@ extern "C" int scp_solver_solve(scp_solver* s, const double* limits, const doubl
     rec->time_sec = now_s() - t_it;
     ++res->n_records;
     if (rel[2] <= o->convergence_tolerance) converged = true;
-    SV_HIP(hipMemcpyAsync(s->acc, s->x, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    std::swap(s->acc, s->x);  // the new iterate and its positions become the next linearisation point
+    std::swap(s->pos_a, s->pos_b);
+    acc = s->acc;
     ++iteration;
     if (o->refresh_feasibility && !converged) {  // opt-in (the reference leaves a TODO, scp.py:150)
-      SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, s->acc, p0, v0, s->pos_a, nullptr));
       SV_CHECK(scp_check_avoidance(ctx, N, K, D, s->R, 0, s->pairs, s->pos_a, s->stats));
-      SV_CHECK(read_stats(s));
+      SV_CHECK(read_stats(s, false));
       is_feasible = s->h_stats->first_violation == UINT64_MAX;
     }
   }
@@ -368,7 +366,8 @@ extern "C" int scp_solver_solve(scp_solver* s, const double* limits, const doubl
     rec->rel_step = -1.0;
     ++res->n_records;
     res->polished = 1;
-    SV_HIP(hipMemcpyAsync(s->acc, s->x, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    std::swap(s->acc, s->x);
+    std::swap(s->pos_a, s->pos_b);
   }
   // final kinematics (scp.py:169)
   SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, s->acc, p0, v0, pos_out, vel_out));

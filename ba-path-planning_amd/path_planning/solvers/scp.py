@@ -170,11 +170,10 @@ class SCP:
 
     def _states(self):
         if "p0" not in self._dev:
-            c, sh = self._ctx, (self.N, self.D)
-            self._dev["p0"] = c.tensor(self.initial_positions.reshape(sh))
-            self._dev["v0"] = c.tensor(self.initial_velocities.reshape(sh))
-            self._dev["pf"] = c.tensor(self.final_positions.reshape(sh))
-            self._dev["vf"] = c.tensor(self.final_velocities.reshape(sh))
+            # one upload for the four arrays (each is a contiguous (N, D) view of it)
+            packed = self._ctx.tensor(np.stack([self.initial_positions, self.initial_velocities, self.final_positions,
+                                                self.final_velocities]).reshape(4, self.N, self.D))
+            self._dev["p0"], self._dev["v0"], self._dev["pf"], self._dev["vf"] = packed[0], packed[1], packed[2], packed[3]
         d = self._dev
         return d["p0"], d["v0"], d["pf"], d["vf"]
 
@@ -272,7 +271,7 @@ class SCP:
         the same library calls in the same order and gives bit-identical results).  The reference's stdout lines are
         printed from the returned records, in the reference's order."""
         start_time = time.time()
-        self._fill_bound_attributes()
+        self._drop_bound_attributes()  # l_* / u_* are recomputed when somebody reads them (see __getattr__)
         if self._native is None:
             known = {k for k, _ in _hip.QpSettings._fields_}
             st = _hip.default_settings(**{k: v for k, v in self._qp_overrides.items() if k in known})
@@ -329,6 +328,21 @@ class SCP:
     def _precompute_constraint_matrices(self):
         p0, v0, pf, vf = self._fill_bound_attributes()
         self._ensure_qp().set_problem(self._limits(), self._space(), p0, v0, pf, vf)
+
+    _BOUND_ATTRS = ("l_jerk", "u_jerk", "l_acc", "u_acc", "l_vel", "u_vel", "l_pos", "u_pos")
+
+    def _drop_bound_attributes(self):
+        for name in self._BOUND_ATTRS:
+            self.__dict__.pop(name, None)
+
+    def __getattr__(self, name):
+        # The native loop does not need the reference's l_* / u_* arrays (scp.py:189-257) on the host; they are built on
+        # first access (one small kernel + a device-to-host copy) instead of once per solve.
+        if (name in SCP._BOUND_ATTRS and self.__dict__.get("initial_positions") is not None
+                and self.__dict__.get("final_positions") is not None):
+            self._fill_bound_attributes()
+            return self.__dict__[name]
+        raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
 
     def _fill_bound_attributes(self):
         """l_* / u_* attributes of the reference (scp.py:189-257), bitwise equal; returns the device states."""

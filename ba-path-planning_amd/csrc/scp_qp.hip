@@ -444,28 +444,29 @@ __global__ __launch_bounds__(256) void add_rows_kernel(int N, int D, int64_t C, 
 }
 
 // scp_qp_reset in one launch (K <= SCP_FUSED_MAX_K): x0 in reference order [N][K][D] (null: zeros) -> x (time-major),
-// z_f = F x, the carried F x and S0 x of the single-step pipeline (exact), y_f = 0.  64 columns per workgroup, the x tile in
-// LDS, every wave takes a quarter of the rows (row coefficients are wave-uniform: scalar loads).
-constexpr int RESET_COLS = 64;
+// z_f = F x, the carried F x and S0 x of the single-step pipeline (exact), y_f = 0.  16 columns per workgroup (256 columns
+// of a 128-agent problem still make 16 workgroups), the x tile in LDS, thread = (column, one sixteenth of the rows).
+constexpr int RESET_COLS = 16;
 __global__ __launch_bounds__(256) void qp_reset_kernel(int N, int K, int D, int Rf, const double* __restrict__ x0,
                                                         const double* __restrict__ F, const double* __restrict__ S0,
                                                         double* __restrict__ x, double* __restrict__ zf,
                                                         double* __restrict__ fx, double* __restrict__ Qx,
                                                         double* __restrict__ yf) {
   extern __shared__ double reset_xs[];  // [K][RESET_COLS]
+  constexpr int RG = 256 / RESET_COLS;
   const int64_t C = (int64_t)N * D;
   const int lc = threadIdx.x & (RESET_COLS - 1), rg = threadIdx.x / RESET_COLS;
   const int64_t c = (int64_t)blockIdx.x * RESET_COLS + lc;
   const bool live = c < C;
   const int64_t agent = live ? c / D : 0;
   const int dim = live ? (int)(c - agent * D) : 0;
-  for (int k = rg; k < K; k += 256 / RESET_COLS) {
+  for (int k = rg; k < K; k += RG) {
     const double v = (live && x0) ? x0[(agent * K + k) * D + dim] : 0.0;
     reset_xs[k * RESET_COLS + lc] = v;
     if (live) x[(int64_t)k * C + c] = v;
   }
   __syncthreads();
-  for (int r = rg; r < Rf + K; r += 256 / RESET_COLS) {
+  for (int r = rg; r < Rf + K; r += RG) {
     const double* __restrict__ row = r < Rf ? F + (size_t)r * K : S0 + (size_t)(r - Rf) * K;
     double acc = 0.0;
     for (int k = 0; k < K; ++k) acc += row[k] * reset_xs[k * RESET_COLS + lc];
@@ -503,6 +504,14 @@ size_t kkt_slot_doubles(int K) {  // Hf, HS, Minv, T + packed HS, Minv, T, each 
   return al((size_t)K * K) * 3 + al((size_t)2 * K * K) + al(scp_packed_count(2 * K, K)) + 2 * al(scp_packed_count(K, K));
 }
 
+// Adaptive rho moves on a geometric grid (steps of 2^(1/4)), so a solver object that is reused from scenario to scenario
+// (compute-trajectories-batch) keeps meeting the same values: short horizons get enough slots to hold them all.
+int kkt_slots(int K) {
+  const size_t per = kkt_slot_doubles(K) * sizeof(double);
+  const size_t fit = SCP_KKT_POOL_BYTES / per;
+  return (int)std::min<size_t>(SCP_KKT_SLOTS_MAX, std::max<size_t>(SCP_KKT_SLOTS, fit));
+}
+
 size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   const int Rf = 4 * K - 1;
   Carver c{static_cast<char*>(ws), 0};
@@ -520,7 +529,7 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.pS0 = c.take<double>(scp_packed_count(K, K));
   d.pS0t = c.take<double>(scp_packed_count(K, K));
   d.pHS = d.pMinv = d.T = d.pT = nullptr;
-  d.kkt_pool = c.take<double>((size_t)SCP_KKT_SLOTS * kkt_slot_doubles(K));
+  d.kkt_pool = c.take<double>((size_t)kkt_slots(K) * kkt_slot_doubles(K));
   const size_t nf = (size_t)Rf * C, nx = (size_t)K * C;
   d.lf = c.take<double>(nf);
   d.uf = c.take<double>(nf);
@@ -626,13 +635,13 @@ int build_kkt(scp_qp* qp) {
   }
   // cache lookup: the blocks of this (rho, sigma) may still be resident
   scp_qp::KktSlot* slot = nullptr;
-  for (auto& k : qp->kkt)
-    if (k.used && k.rho == qp->rho && k.sigma == qp->st.sigma) slot = &k;
+  for (int i = 0; i < qp->n_kkt; ++i)
+    if (qp->kkt[i].used && qp->kkt[i].rho == qp->rho && qp->kkt[i].sigma == qp->st.sigma) slot = &qp->kkt[i];
   const bool hit = slot != nullptr;
   if (!hit) {
     slot = &qp->kkt[0];
-    for (auto& k : qp->kkt)
-      if (k.used < slot->used) slot = &k;  // empty (0) or least recently used
+    for (int i = 0; i < qp->n_kkt; ++i)
+      if (qp->kkt[i].used < slot->used) slot = &qp->kkt[i];  // empty (0) or least recently used
   }
   slot->used = ++qp->kkt_clock;
   d.Hf = slot->Hf; d.HS = slot->HS; d.Minv = slot->Minv; d.T = slot->T;
@@ -851,7 +860,9 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
   {
     auto al = [](size_t n) { return (n + 31) / 32 * 32; };
     double* base = qp->d.kkt_pool;
-    for (auto& k : qp->kkt) {
+    qp->n_kkt = kkt_slots(K);
+    for (int i = 0; i < qp->n_kkt; ++i) {
+      auto& k = qp->kkt[i];
       double* q = base;
       k.rho = k.sigma = 0.0;
       k.used = 0;

@@ -2,7 +2,9 @@
 #pragma once
 #include "scp_common.h"
 
-constexpr int SCP_KKT_SLOTS = 6;  // cached rho values per solver object
+constexpr int SCP_KKT_SLOTS = 6;       // cached rho values per solver object: at least this many ...
+constexpr int SCP_KKT_SLOTS_MAX = 32;  // ... and up to this many while the pool stays below SCP_KKT_POOL_BYTES
+constexpr size_t SCP_KKT_POOL_BYTES = (size_t)48 << 20;
 constexpr int NPART = 128;  // partial sums of a dot product (fixed -> deterministic summation order)
 
 enum Slot {  // device scalar slots (doubles)
@@ -47,7 +49,7 @@ struct QpDev {
   double* gval2;  // [2 cap]   row vectors of a termination check: yc ...
   double* gval3;  // [2 cap]   ... and delta-yc (gval keeps the pipeline's values across a check)
   int *pos_i, *pos_j;  // [cap] entry positions of row n
-  double* kkt_pool;  // SCP_KKT_SLOTS cache slots of the rho-dependent blocks
+  double* kkt_pool;  // scp_kkt_slots(K) cache slots of the rho-dependent blocks
   unsigned long long* sync_words;  // SCP_SYNC_WORDS: give-up word of the persistent kernel, scratch
   unsigned long long* cells;       // [K][N][D][2] tagged granules: S0 p cells published by the persistent kernel
   unsigned long long* gpart;       // SCP_GPART_WORDS tagged granules: line-search partials, two alternating buffers
@@ -75,7 +77,8 @@ struct scp_qp {
     double rho, sigma;
     unsigned long long used;  // LRU stamp, 0 = empty
     double *Hf, *HS, *Minv, *T, *pHS, *pMinv, *pT;
-  } kkt[SCP_KKT_SLOTS];
+  } kkt[SCP_KKT_SLOTS_MAX];
+  int n_kkt;  // slots in use for this K (scp_kkt_slots)
   unsigned long long kkt_clock;
   bool consts_packed;  // F, F^T, S0, S0^T are packed once
   double* h_scal;  // pinned, SL_COUNT + SCP_RESID_CAP doubles + the completion flag of a fused check

@@ -186,6 +186,9 @@ def build_parser():
     p.add_argument("--fresh-solvers", action="store_true",
                    help="build a new solver object for every trial like the reference (:32-38) instead of reusing one per worker")
     p.add_argument("--validate", action="store_true", help="add the minimum pair distance of every result to its record")
+    p.add_argument("--warmup", type=int, default=0,
+                   help="untimed solves per worker (stream) before the clock starts: the first solve of a worker builds its "
+                        "solver object and loads the kernels (~0.1 s); with it the scenarios/s line is the steady-state rate")
     p.add_argument("--streams", type=int, default=1,
                    help="solve this many scenarios concurrently on one GPU, each on its own HIP stream (a solve of "
                         "~100 agents is latency bound and leaves the GPU mostly idle)")
@@ -271,15 +274,9 @@ def main(argv=None):
         print(f"  [rank {rank}] N={N} trial {trial+1:02d}/{cfg['trials_per_N']}  time = {res['time_sec']:.3f}s  [{status_str}]")
         return res
 
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.barrier()  # all ranks start their timed loops together (scenario generation takes different times)
-    wall_start = time.time()
-    t_all = time.perf_counter()
-    if args.streams <= 1:
-        runs = [one_job(j) for j in jobs]
-    else:
+    executor = None
+    on_stream = None
+    if args.streams > 1:
         # scenario-parallel on ONE GPU: a worker thread per HIP stream; ctypes releases the GIL inside the library
         # and every SCP object owns its context, workspace and stream, so the solves overlap on the device
         import threading
@@ -296,12 +293,41 @@ def main(argv=None):
             with torch.cuda.stream(tls.stream):
                 return one_job(job)
 
-        with ThreadPoolExecutor(max_workers=args.streams) as pool:
+        executor = ThreadPoolExecutor(max_workers=args.streams)
+    if args.warmup > 0 and jobs and not args.fresh_solvers:
+        import contextlib
+        import io
+
+        quiet = io.StringIO()
+        with contextlib.redirect_stdout(quiet):
+            if executor is None:
+                for _ in range(args.warmup):
+                    one_job(jobs[0])
+            else:
+                gate = threading.Barrier(args.streams)  # every worker thread takes exactly one warm-up task
+
+                def warm(_):
+                    gate.wait()
+                    for _ in range(args.warmup):
+                        on_stream(jobs[0])
+
+                list(executor.map(warm, range(args.streams)))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()  # all ranks start their timed loops together (scenario generation takes different times)
+    wall_start = time.time()
+    t_all = time.perf_counter()
+    if executor is None:
+        runs = [one_job(j) for j in jobs]
+    else:
+        with executor as pool:
             runs = list(pool.map(on_stream, jobs))
     wall = time.perf_counter() - t_all
     if jobs:
         print(f"  [rank {rank}] {len(jobs)} scenarios in {wall:.2f}s wall = {len(jobs)/wall:.1f} scenarios/s "
-              f"({args.streams} stream(s); scenario generation {t_gen:.2f}s before the clock)")
+              f"({args.streams} stream(s); scenario generation {t_gen:.2f}s"
+              f"{f' and {args.warmup} warm-up solve(s) per stream' if args.warmup > 0 else ''} before the clock)")
 
     wall_end = time.time()
     if world > 1:

@@ -92,6 +92,29 @@ def test_batch_cli_config5(tmp_path, capsys):
     assert [int(q["iter"]) for q in [solver.last_info["qp0"]] + solver.last_info["iterations"]] == rec["qp_iterations"]
 
 
+def test_batch_cli_streams_give_identical_records(tmp_path, capsys):
+    """Config 5's scenario-parallel mode (worker threads, one HIP stream and one reused solver object each, warm-up solve)
+    against the one-at-a-time path: same scenarios -> the same waypoints bit for bit and the same iteration counts.  (If a
+    persistent QP kernel ever gave up under co-scheduling, its solve would continue on the three-launch pipeline and
+    differ at the 1e-9 level: the bitwise comparison would show it.)"""
+    from path_planning.cli import compute_trajectories_batch as cli
+
+    common = ["--Ns", "128", "--trials", "8", "--scenario", "grid-swap", "--seed", "11", "--save-trajectories"]
+    one = cli.main(common + ["--results-dir", str(tmp_path / "one")])
+    par = cli.main(common + ["--results-dir", str(tmp_path / "par"), "--streams", "4", "--warmup", "1"])
+    out = capsys.readouterr().out
+    assert "4 stream(s)" in out and "1 warm-up solve(s) per stream" in out
+    assert len(one["runs"]) == len(par["runs"]) == 8
+    for a, b in zip(one["runs"], par["runs"]):
+        assert a["status"] == b["status"] == "success" and a["seed"] == b["seed"] and a["trial_index"] == b["trial_index"]
+        assert a["qp_iterations"] == b["qp_iterations"] and a["scp_iterations"] == b["scp_iterations"]
+        assert a["working_rows"] == b["working_rows"] and a["rel_steps"] == b["rel_steps"]
+        ta = np.load(tmp_path / "one" / a["trajectory_file"])
+        tb = np.load(tmp_path / "par" / b["trajectory_file"])
+        for key in ("positions", "velocities", "accelerations"):
+            np.testing.assert_array_equal(ta[key], tb[key])
+
+
 @pytest.mark.parametrize("cg,tol", [(2, 1e-6), (1, 2e-2)])
 def test_scp_128_agents_vs_c_oracle(cg, tol):
     """The unit of config 5: one 128-agent grid-swap solve against the C oracle's SCP loop.  Two PCG steps: iterate for

@@ -140,6 +140,8 @@ int solve_joint_qp(scp_solver* s, const double* acc_in, const double* limits, co
     if ((int64_t)s->h_stats->n_selected <= s->sel_cap) break;
     SV_CHECK(grow_sel(s, (int64_t)s->h_stats->n_selected));
   }
+  float lin_ms = 0.f, viol_ms = 0.f;
+  if (s->pairs > 0) SV_CHECK(scp_ctx_last_pair_ms(ctx, &lin_ms));  // (that kernel has finished: its stats were read)
   int64_t n = (int64_t)s->h_stats->n_selected;
   SV_CHECK(scp_qp_update_settings(s->qp, &s->st));
   SV_CHECK(scp_qp_reset(s->qp, acc_in));
@@ -173,6 +175,7 @@ int solve_joint_qp(scp_solver* s, const double* acc_in, const double* limits, co
       if ((int64_t)s->h_stats->n_selected <= s->sel_cap) break;
       SV_CHECK(grow_sel(s, (int64_t)s->h_stats->n_selected));
     }
+    if (s->pairs > 0) SV_CHECK(scp_ctx_last_pair_ms(ctx, &viol_ms));
     n = (int64_t)s->h_stats->n_selected;
     max_v = s->h_stats->max_violation;
     if (rounds < SCP_MAX_ROUNDS_RECORDED) rec->added[rounds] = n;
@@ -189,6 +192,8 @@ int solve_joint_qp(scp_solver* s, const double* acc_in, const double* limits, co
   rec->rounds = rounds;
   rec->unresolved_rows = n;
   rec->max_violation = max_v;
+  rec->linearize_ms = lin_ms;
+  rec->violations_ms = viol_ms;
   s->st = saved;
   return SCP_OK;
 }
@@ -374,5 +379,26 @@ extern "C" int scp_solver_solve(scp_solver* s, const double* limits, const doubl
   SV_HIP(hipMemcpyAsync(acc_out, s->acc, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
   SV_HIP(hipStreamSynchronize(ctx->stream));
   res->time_sec = now_s() - t_start;
+  return SCP_OK;
+}
+
+extern "C" int scp_solver_step(scp_solver* s, const double* limits, const double* space, const double* p0, const double* v0,
+                               const double* pf, const double* vf, const scp_solve_options* o, const double* acc_in,
+                               double* acc_out, scp_qp_record* rec) {
+  if (!s) return SCP_ERR_INVALID;
+  scp_ctx* ctx = s->ctx;
+  SCP_REQUIRE(ctx, limits && space && p0 && v0 && pf && vf && o && acc_in && acc_out && rec, "solver_step: null pointer");
+  const int N = s->N, K = s->K, D = s->D;
+  const size_t nbytes = (size_t)N * K * D * sizeof(double);
+  const double t0 = now_s();
+  SV_CHECK(scp_qp_set_problem(s->qp, limits, space, p0, v0, pf, vf));
+  SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, acc_in, p0, v0, s->pos_a, nullptr));
+  SV_CHECK(solve_joint_qp(s, acc_in, limits, space, p0, v0, pf, vf, o, 0.0, rec));
+  double rel[3];
+  SV_CHECK(scp_rel_step(ctx, (int64_t)N * K * D, s->x, acc_in, rel));  // scp.py:157-159
+  rec->rel_step = rel[2];
+  SV_HIP(hipMemcpyAsync(acc_out, s->x, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+  SV_HIP(hipStreamSynchronize(ctx->stream));
+  rec->time_sec = now_s() - t0;
   return SCP_OK;
 }

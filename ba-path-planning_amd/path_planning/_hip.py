@@ -60,6 +60,7 @@ class QpRecord(C.Structure):
         ("rounds", C.c_int32), ("reserved", C.c_int32), ("working_rows", C.c_int64), ("unresolved_rows", C.c_int64),
         ("added", C.c_int64 * MAX_ROUNDS_RECORDED), ("r_prim", C.c_double), ("r_dual", C.c_double), ("rho", C.c_double),
         ("solve_ms", C.c_double), ("max_violation", C.c_double), ("rel_step", C.c_double), ("time_sec", C.c_double),
+        ("linearize_ms", C.c_double), ("violations_ms", C.c_double),
     ]
 
     def as_dict(self):
@@ -70,6 +71,7 @@ class QpRecord(C.Structure):
         d["added"] = [int(self.added[i]) for i in range(min(self.rounds, MAX_ROUNDS_RECORDED))]
         d["unresolved_rows"] = int(self.unresolved_rows)
         d["max_violation"] = float(self.max_violation)
+        d["linearize_ms"], d["violations_ms"] = float(self.linearize_ms), float(self.violations_ms)
         return d
 
 
@@ -108,6 +110,7 @@ EXPORTS = [
     "scp_qp_reset", "scp_qp_add_rows", "scp_qp_solve", "scp_qp_clone_state", "scp_qp_get_solution",
     "scp_qp_get_duals", "scp_gemm_f64", "scp_qp_peek", "scp_qp_debug_set",
     "scp_solve_default_options", "scp_solver_create", "scp_solver_destroy", "scp_solver_update_settings", "scp_solver_solve",
+    "scp_solver_step",
 ]
 
 
@@ -173,6 +176,7 @@ def load_library():
     lib.scp_solver_destroy.argtypes = [vp]
     lib.scp_solver_destroy.restype = None
     lib.scp_solver_update_settings.argtypes = [vp, C.POINTER(QpSettings)]
+    lib.scp_solver_step.argtypes = [vp, pd, pd, vp, vp, vp, vp, C.POINTER(SolveOptions), vp, vp, C.POINTER(QpRecord)]
     lib.scp_solver_solve.argtypes = [vp, pd, pd, vp, vp, vp, vp, C.POINTER(SolveOptions), vp, vp, vp, C.POINTER(SolveResult),
                                      C.POINTER(QpRecord), i32]
     _LIB, _LIB_PATH = lib, path
@@ -511,3 +515,14 @@ class NativeSolver:
                                        C.byref(options), acc.data_ptr(), pos.data_ptr(), vel.data_ptr(), C.byref(res), recs,
                                        cap))
         return acc, pos, vel, res, [recs[i] for i in range(res.n_records)]
+
+    def step(self, limits, space, p0, v0, pf, vf, options: SolveOptions, acc):
+        """One SCP iteration from the accelerations `acc` (device (N, K, D)) -> (new accelerations, QpRecord)."""
+        c = self.ctx
+        out = c.empty(self.N, self.K, self.D)
+        la, lp = _harr(limits)
+        sa, sp = _harr(space)
+        rec = QpRecord()
+        c.check(c.lib.scp_solver_step(self.h_solver, lp, sp, p0.data_ptr(), v0.data_ptr(), pf.data_ptr(), vf.data_ptr(),
+                                      C.byref(options), acc.data_ptr(), out.data_ptr(), C.byref(rec)))
+        return out, rec

@@ -266,25 +266,45 @@ class SCP:
         self._print(f"Trajectory generation completed in {end_time - start_time:.3f} seconds")
         return self.trajectories
 
+    def _ensure_native(self):
+        if self._native is None:
+            known = {k for k, _ in _hip.QpSettings._fields_}
+            st = _hip.default_settings(**{k: v for k, v in self._qp_overrides.items() if k in known})
+            self._native = _hip.NativeSolver(self._ctx, self.N, self.K, self.D, self.h, self.R, st,
+                                             row_capacity=self._qp_row_capacity)
+        return self._native
+
+    def _native_options(self, max_iterations=15):
+        return self._ensure_native().default_options(
+            max_iterations=int(max_iterations), max_rounds=self.max_rounds,
+            max_iter0=int(self._qp_overrides.get("max_iter0", self._qp_overrides.get("max_iter", 4000))),
+            max_iter=int(self._qp_overrides.get("max_iter", 10000)), refresh_feasibility=int(self.refresh_feasibility),
+            polish=int(self.polish), working_set_margin=self.working_set_margin, feasibility_tol=self.feasibility_tol,
+            polish_eps=self.polish_eps, convergence_tolerance=self.convergence_tolerance)
+
+    def scp_iteration(self, accelerations):
+        """ONE pass of the SCP loop body (scp.py:152-166) in one library call (scp_solver_step): linearise around
+        `accelerations` (device (N, K, D)), joint QP, relative step.  Returns (new accelerations, info dict).  This is what
+        bench.py times; generate_trajectories runs the same code in its native loop."""
+        if self.shard.world != 1:
+            raise RuntimeError("scp_iteration: single-rank only (the sharded loop is driven from Python)")
+        nat = self._ensure_native()
+        p0, v0, pf, vf = self._states()
+        new, rec = nat.step(self._limits(), self._space(), p0, v0, pf, vf, self._native_options(),
+                            self._to_device_acc(accelerations))
+        info = dict(rec.as_dict(), rel_step=float(rec.rel_step), time_sec=float(rec.time_sec))
+        self._last_qp_info = info
+        return new, info
+
     def _generate_trajectories_native(self, max_iterations):
         """generate_trajectories with the loop driven by scp_solver_solve (one C call; the Python-driven loop above makes
         the same library calls in the same order and gives bit-identical results).  The reference's stdout lines are
         printed from the returned records, in the reference's order."""
         start_time = time.time()
         self._drop_bound_attributes()  # l_* / u_* are recomputed when somebody reads them (see __getattr__)
-        if self._native is None:
-            known = {k for k, _ in _hip.QpSettings._fields_}
-            st = _hip.default_settings(**{k: v for k, v in self._qp_overrides.items() if k in known})
-            self._native = _hip.NativeSolver(self._ctx, self.N, self.K, self.D, self.h, self.R, st,
-                                             row_capacity=self._qp_row_capacity)
-        nat = self._native
+        nat = self._ensure_native()
         p0, v0, pf, vf = self._states()
-        opts = nat.default_options(
-            max_iterations=int(max_iterations), max_rounds=self.max_rounds,
-            max_iter0=int(self._qp_overrides.get("max_iter0", self._qp_overrides.get("max_iter", 4000))),
-            max_iter=int(self._qp_overrides.get("max_iter", 10000)), refresh_feasibility=int(self.refresh_feasibility),
-            polish=int(self.polish), working_set_margin=self.working_set_margin, feasibility_tol=self.feasibility_tol,
-            polish_eps=self.polish_eps, convergence_tolerance=self.convergence_tolerance)
+        opts = self._native_options(max_iterations)
         acc, pos, vel, res, recs = nat.solve(self._limits(), self._space(), p0, v0, pf, vf, opts)
         qp0 = dict(recs[0].as_dict(), rounds=1, added=[])
         self._last_qp_info = qp0

@@ -126,9 +126,13 @@ def main():
     pp = solver._ensure_pairs()
 
     def step():
-        new = solver._solve_with_avoidance_constraints(acc0)
+        """-> (new accelerations, rel. step, device ms of the linearisation kernel, of the last violations kernel)"""
+        if world == 1:  # the loop body as ONE library call (scp_solver_step): what generate_trajectories runs per iteration
+            new, info = solver.scp_iteration(acc0)
+            return new, info["rel_step"], info["linearize_ms"], info["violations_ms"]
+        new = solver._solve_with_avoidance_constraints(acc0)  # sharded: the same calls driven from Python + collectives
         rel = solver._ctx.rel_step(new, acc0)[2]
-        return new, rel
+        return new, rel, pp.last_linearize_ms, pp.last_violations_ms
 
     def barrier():
         if world > 1:
@@ -141,9 +145,9 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        _, rel = step()
-        lin_ms.append(pp.last_linearize_ms)
-        viol_ms.append(pp.last_violations_ms)
+        _, rel, lms, vms = step()
+        lin_ms.append(lms)
+        viol_ms.append(vms)
         infos.append(dict(solver._last_qp_info, rel_step=rel))
     barrier()
     dt = time.perf_counter() - t0
@@ -213,7 +217,7 @@ def main():
     if traffic_note:
         out["roofline"]["traffic_note"] = traffic_note
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        x_gpu, _ = step()
+        x_gpu = step()[0]
         out["cpu_baseline"] = cpu_baseline(N, K, D, h, T, R, space, p0, pf, solver.working_set_margin, infos[-1],
                                            acc0.cpu().numpy(), x_gpu.cpu().numpy())
         out["parity_max_abs"] = out["cpu_baseline"]["parity_max_abs"]

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SCP_ABI_VERSION 2
+#define SCP_ABI_VERSION 3
 
 typedef enum scp_status {
   SCP_OK = 0,
@@ -235,6 +235,8 @@ typedef struct scp_qp_record {
   double r_prim, r_dual, rho, solve_ms, max_violation;
   double rel_step;          /* ||a_new - a_prev|| / ||a_prev|| (scp.py:157-159); -1 for QP#0 / polish */
   double time_sec;          /* wall time of the SCP iteration */
+  double linearize_ms;      /* device time of the linearisation kernel alone (HIP events around that launch) */
+  double violations_ms;     /* device time of the last violations kernel */
 } scp_qp_record;
 
 typedef struct scp_solve_result {
@@ -258,6 +260,14 @@ int scp_solver_update_settings(scp_solver* s, const scp_qp_settings* st);
 int scp_solver_solve(scp_solver* s, const double* limits, const double* space, const double* p0, const double* v0,
                      const double* pf, const double* vf, const scp_solve_options* o, double* acc_out, double* pos_out,
                      double* vel_out, scp_solve_result* res, scp_qp_record* records, int record_capacity);
+
+/* ONE SCP iteration (the loop body scp.py:152-166 without the convergence decision): linearise around acc_in, joint QP with
+ * exact constraint generation, relative step -> *rec [host] (rel_step, time_sec, linearize_ms ... filled), acc_out = the new
+ * accelerations ([N][K][D] device, may alias nothing).  Same calls in the same order as one pass of scp_solver_solve's loop;
+ * bench.py times this call.  Synchronises the stream before returning. */
+int scp_solver_step(scp_solver* s, const double* limits, const double* space, const double* p0, const double* v0,
+                    const double* pf, const double* vf, const scp_solve_options* o, const double* acc_in, double* acc_out,
+                    scp_qp_record* rec);
 
 /* ---- test hooks (dense K-dimension products used by the QP; exercised by tests/test_kernels_gpu.py::test_gemm_f64) ------
  * Y[R][C] = alpha * A[R][M] X[M][C] + beta * Y, row-major, device pointers. */

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_hip.EXPORTS), declared ^ set(_hip.EXPORTS)
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert lib.scp_abi_version() == 2
+    assert lib.scp_abi_version() == 3
     # struct layouts agree with the header
     import subprocess
     import tempfile

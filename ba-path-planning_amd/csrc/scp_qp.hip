@@ -57,46 +57,6 @@ __global__ __launch_bounds__(256) void admm_rhs_prep_kernel(int64_t nf, int64_t 
 
 enum RowMode { ROW_RHS = 0, ROW_HMUL = 1, ROW_Y = 2, ROW_VEC = 3 };
 
-// G[k][i] += eta g, G[k][j] -= eta g  for every working row; g depends on the mode:
-//   ROW_RHS : rho zc - yc            (right-hand side of the x-update)
-//   ROW_HMUL: rho eta.(Q_i - Q_j)    (A_W^T R_c A_W v, Q = S0 v)
-//   ROW_Y   : yc                     (A_W^T y for the dual residual)
-template <int D, int MODE>
-__global__ __launch_bounds__(256) void row_scatter_kernel(int64_t nW, int64_t C, double rho,
-                                                           const int* __restrict__ wk, const int* __restrict__ wi,
-                                                           const int* __restrict__ wj,
-                                                           const double* __restrict__ weta,
-                                                           const double* __restrict__ zc,
-                                                           const double* __restrict__ yc,
-                                                           const double* __restrict__ Q, double* __restrict__ G) {
-  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n >= nW) return;
-  const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
-  const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
-  double e[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) e[d] = weta[n * D + d];
-  double g;
-  if (MODE == ROW_RHS) {
-    g = rho * zc[n] - yc[n];
-  } else if (MODE == ROW_HMUL) {
-    double ax = 0.0;
-#pragma unroll
-    for (int d = 0; d < D; ++d) ax += e[d] * (Q[bi + d] - Q[bj + d]);
-    g = rho * ax;
-  } else if (MODE == ROW_Y) {
-    g = yc[n];
-  } else {
-    g = zc[n];  // ROW_VEC: the caller passes an arbitrary row vector through the zc argument
-  }
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    const double c = e[d] * g;
-    atomicAdd(G + bi + d, c);
-    atomicAdd(G + bj + d, -c);
-  }
-}
-
 // r = rhs - Hx
 __global__ __launch_bounds__(256) void cg_residual_kernel(int64_t n, const double* __restrict__ rhs,
                                                            const double* __restrict__ Hx, double* __restrict__ r) {
@@ -590,20 +550,17 @@ int gemm(scp_qp* qp, int R, int M, double alpha, const double* A, const double* 
   return scp_launch_gemm(qp->ctx, qp->st.use_mfma, R, M, (int)qp->C, alpha, A, X, beta, Y);
 }
 
+// G = A_W^T g over the working rows, g by mode (a gather over the sorted incidence lists: fixed summation order; the
+// round-1 version scattered with atomics):
+//   ROW_RHS : rho zc - yc            (right-hand side of the x-update)
+//   ROW_HMUL: rho eta.(Q_i - Q_j)    (A_W^T R_c A_W v, Q = S0 v)
+//   ROW_Y   : yc                     (A_W^T y for the dual residual)
+//   ROW_VEC : vec                    (an arbitrary row vector)
 template <int MODE>
 int row_scatter(scp_qp* qp, const double* Q, const double* vec = nullptr) {
-  const QpDev& d = qp->d;
-  hipStream_t s = qp->ctx->stream;
-  SCP_HIP_CHECK(qp->ctx, hipMemsetAsync(d.G, 0, (size_t)qp->K * qp->C * sizeof(double), s));
-  const double rho_c = qp->rho * qp->st.rho_col_scale;
-  if (qp->D == 2)
-    hipLaunchKernelGGL((row_scatter_kernel<2, MODE>), grid1(qp->nW), dim3(256), 0, s, qp->nW, qp->C, rho_c, d.w_k,
-                       d.w_i, d.w_j, d.w_eta, vec ? vec : d.zc, d.yc, Q, d.G);
-  else
-    hipLaunchKernelGGL((row_scatter_kernel<3, MODE>), grid1(qp->nW), dim3(256), 0, s, qp->nW, qp->C, rho_c, d.w_k,
-                       d.w_i, d.w_j, d.w_eta, vec ? vec : d.zc, d.yc, Q, d.G);
-  QP_LAUNCHED(qp);
-  return SCP_OK;
+  if (!qp->csr_valid) QP_CHECK(scp_qp_csr_build(qp));
+  if (MODE == ROW_HMUL) return scp_qp_rows_gather(qp, false, Q);
+  return scp_qp_csr_scatter(qp, MODE == ROW_RHS ? 0 : (MODE == ROW_Y ? 1 : 2), vec);
 }
 
 // HQ[0:K] = H v = Hf v + A_W^T R_c A_W v ; HQ[K:2K] = S0 v
@@ -764,8 +721,7 @@ int residuals(scp_qp* qp, bool with_dy) {
       hipLaunchKernelGGL(resid_rows_kernel<3>, dim3(blocks), dim3(256), 0, s, qp->nW, C, d.w_k, d.w_i, d.w_j, d.w_eta,
                          d.HQ + nx, d.zc, d.scal);
     QP_LAUNCHED(qp);
-    if (qp->csr_valid) QP_CHECK(scp_qp_csr_scatter(qp, 1, nullptr));
-    else QP_CHECK(row_scatter<ROW_Y>(qp, nullptr));
+    QP_CHECK(row_scatter<ROW_Y>(qp, nullptr));
     QP_CHECK(gemm(qp, K, K, 1.0, d.S0t, d.G, 1.0, d.rhs));
   }
   hipLaunchKernelGGL(resid_dual_kernel, dim3(128), dim3(256), 0, s, nx, d.x, d.rhs, d.scal);
@@ -785,8 +741,7 @@ int certificate_atdy(scp_qp* qp) {
   SCP_HIP_CHECK(ctx, hipMemsetAsync(d.scal + SL_NATDY, 0, sizeof(double), s));
   QP_CHECK(gemm(qp, K, Rf, 1.0, d.Ft, d.dyf, 0.0, d.rhs));
   if (qp->nW > 0) {
-    if (qp->csr_valid) QP_CHECK(scp_qp_csr_scatter(qp, 2, d.dyc));
-    else QP_CHECK(row_scatter<ROW_VEC>(qp, nullptr, d.dyc));
+    QP_CHECK(row_scatter<ROW_VEC>(qp, nullptr, d.dyc));
     QP_CHECK(gemm(qp, K, K, 1.0, d.S0t, d.G, 1.0, d.rhs));
   }
   hipLaunchKernelGGL(max_abs_kernel, dim3(128), dim3(256), 0, s, nx, d.rhs, d.scal + SL_NATDY);

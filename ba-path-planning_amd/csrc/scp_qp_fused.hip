@@ -182,35 +182,8 @@ __global__ __launch_bounds__(FT) void fused_pre_kernel(int K, int Rf, int64_t C,
   }
 }
 
-// ---- K_B / K_D: working rows, G += eta g ----------------------------------------------------------------
-//   INIT: g = rho zc - yc - rho eta.(Qx_i - Qx_j)     (rhs minus H x of the collision part)
-//   HMUL: g = rho eta.(Qp_i - Qp_j)
-template <int D, bool INIT>
-__global__ __launch_bounds__(256) void fused_rows_kernel(int64_t nW, int64_t C, double rho, const int* __restrict__ wk,
-                                                          const int* __restrict__ wi, const int* __restrict__ wj,
-                                                          const double* __restrict__ weta,
-                                                          const double* __restrict__ zc, const double* __restrict__ yc,
-                                                          const double* __restrict__ Q, double* __restrict__ G) {
-  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n >= nW) return;
-  const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
-  const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
-  double e[D], ax = 0.0;
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    e[d] = weta[n * D + d];
-    ax += e[d] * (Q[bi + d] - Q[bj + d]);
-  }
-  double g = rho * ax;
-  if (INIT) g = (rho * zc[n] - yc[n]) - g;
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    const double c = e[d] * g;
-    atomicAdd(G + bi + d, c);
-    atomicAdd(G + bj + d, -c);
-  }
-}
-
+// ---- K_B / K_D: working rows, G = A_W^T g: rows_value_kernel + csr_gather_kernel (scp_qp_rows_gather below) -- a gather
+// over the sorted incidence lists, so the sums have a fixed order (the round-1 version scattered with atomics)
 // ---- K_C: PCG start ---------------------------------------------------------------------------------------
 // r = r0 + S0^T G ; zz = Minv r ; p = zz ; part[b] = r.zz ; [HpF ; Qp] = [H_f ; S0] p ; G = 0
 __global__ __launch_bounds__(FT) void fused_cg_init_kernel(int K, int64_t C, const double* __restrict__ S0t,
@@ -1090,22 +1063,25 @@ __global__ __launch_bounds__(256) void cg1_update_kernel(int K, int Rf, int64_t 
   gval[posj] = g;
 }
 
-// row values of the first right-hand side after (x, zc, yc, rho) changed outside the pipeline (S0 x exact in Qx)
-template <int D>
-__global__ __launch_bounds__(256) void cg1_rows_init_kernel(int64_t nW, int64_t C, double rho, const int* __restrict__ wk,
-                                                             const int* __restrict__ wi, const int* __restrict__ wj,
-                                                             const double* __restrict__ weta, const double* __restrict__ Qx,
-                                                             const double* __restrict__ zc, const double* __restrict__ yc,
-                                                             const int* __restrict__ pos_i, const int* __restrict__ pos_j,
-                                                             double* __restrict__ gval) {
+// row values g written to BOTH incidence-list entries of a row (pos_i, pos_j); the per-cell gathers then need no atomics:
+//   INIT: g = (rho zc - yc) - rho eta.(Q_i - Q_j)   right-hand side minus the collision part of H x (Q = S0 x); also the
+//         first row values of the single-step pipeline after (x, zc, yc, rho) changed outside it
+//   else: g = rho eta.(Q_i - Q_j)                   collision part of H v (Q = S0 v)
+template <int D, bool INIT>
+__global__ __launch_bounds__(256) void rows_value_kernel(int64_t nW, int64_t C, double rho, const int* __restrict__ wk,
+                                                          const int* __restrict__ wi, const int* __restrict__ wj,
+                                                          const double* __restrict__ weta, const double* __restrict__ Q,
+                                                          const double* __restrict__ zc, const double* __restrict__ yc,
+                                                          const int* __restrict__ pos_i, const int* __restrict__ pos_j,
+                                                          double* __restrict__ gval) {
   const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (n >= nW) return;
   const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
   const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
   double ax = 0.0;
 #pragma unroll
-  for (int d = 0; d < D; ++d) ax += weta[n * D + d] * (Qx[bi + d] - Qx[bj + d]);
-  const double g = (rho * zc[n] - yc[n]) - rho * ax;
+  for (int d = 0; d < D; ++d) ax += weta[n * D + d] * (Q[bi + d] - Q[bj + d]);
+  const double g = INIT ? (rho * zc[n] - yc[n]) - rho * ax : rho * ax;
   gval[pos_i[n]] = g;
   gval[pos_j[n]] = g;
 }
@@ -1150,26 +1126,20 @@ int scp_qp_fused_iteration(scp_qp* qp, int* cg_count) {
                      has_rows, d.pFt, d.pHS, d.pMinv, d.wrow, d.x, d.zf, d.yf, d.rhs, Q, d.xt, d.G);
   FUSED_LAUNCHED(qp);
   if (has_rows) {
-    if (qp->D == 2)
-      hipLaunchKernelGGL((fused_rows_kernel<2, true>), rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
-                         d.w_eta, d.zc, d.yc, Q, d.G);
-    else
-      hipLaunchKernelGGL((fused_rows_kernel<3, true>), rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
-                         d.w_eta, d.zc, d.yc, Q, d.G);
-    FUSED_LAUNCHED(qp);
+    {
+      int rc = scp_qp_rows_gather(qp, true, Q);
+      if (rc) return rc;
+    }
     hipLaunchKernelGGL(fused_cg_init_kernel, cgrid, cblock, (size_t)(5 * K) * tile, s, K, C, d.pS0t, d.pMinv, d.pHS, d.rhs,
                        d.G, d.r, d.p, d.hpf, Q, part_rz);
     FUSED_LAUNCHED(qp);
     int slot = SL_RZ0;
     const int ncg = qp->st.cg_iters;
     for (int it = 0; it < ncg; ++it) {
-      if (qp->D == 2)
-        hipLaunchKernelGGL((fused_rows_kernel<2, false>), rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
-                           d.w_eta, d.zc, d.yc, Q, d.G);
-      else
-        hipLaunchKernelGGL((fused_rows_kernel<3, false>), rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j,
-                           d.w_eta, d.zc, d.yc, Q, d.G);
-      FUSED_LAUNCHED(qp);
+      {
+        int rc = scp_qp_rows_gather(qp, false, Q);
+        if (rc) return rc;
+      }
       hipLaunchKernelGGL(fused_cg_hp_kernel, cgrid, cblock, (size_t)(2 * K) * tile, s, K, C, d.pS0t, d.G, d.hpf, d.p, Hp,
                          part_php);
       FUSED_LAUNCHED(qp);
@@ -1274,10 +1244,10 @@ int scp_qp_cg1_prepare(scp_qp* qp) {
   }
   const dim3 rgrid((unsigned)((qp->nW + 255) / 256)), rblock(256);
   if (qp->D == 2)
-    hipLaunchKernelGGL(cg1_rows_init_kernel<2>, rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j, d.w_eta, Qx,
+    hipLaunchKernelGGL((rows_value_kernel<2, true>), rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j, d.w_eta, Qx,
                        d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
   else
-    hipLaunchKernelGGL(cg1_rows_init_kernel<3>, rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j, d.w_eta, Qx,
+    hipLaunchKernelGGL((rows_value_kernel<3, true>), rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j, d.w_eta, Qx,
                        d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
   FUSED_LAUNCHED(qp);
   qp->cg1_ready = true;
@@ -1460,7 +1430,7 @@ __global__ __launch_bounds__(256) void csr_finish_kernel(int64_t nent, int D, co
 }
 
 // Small problems (N K <= CSR1_MAX_CELLS cells, e.g. 128 agents x 50 steps): the whole build -- count, scan, fill, sort,
-// finish -- and the first row values (cg1_rows_init_kernel) in ONE workgroup; the cell counters live in LDS.  Same lists,
+// finish -- and the first row values (rows_value_kernel<D, true>) in ONE workgroup; the cell counters live in LDS.  Same lists,
 // same order as the five-launch build.
 __global__ __launch_bounds__(1024) void csr_small_kernel(int64_t nW, int K, int ncell, int D, int64_t C, double rho,
                                                           const int* __restrict__ wk, const int* __restrict__ wi,
@@ -1535,7 +1505,7 @@ __global__ __launch_bounds__(1024) void csr_small_kernel(int64_t nW, int K, int 
     else pos_i[n] = (int)t;
   }
   __syncthreads();
-  for (int64_t n = tid; n < nW; n += 1024) {  // cg1_rows_init_kernel
+  for (int64_t n = tid; n < nW; n += 1024) {  // rows_value_kernel<D, true>
     const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
     const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
     double ax = 0.0;
@@ -1611,6 +1581,35 @@ int scp_qp_csr_scatter(scp_qp* qp, int mode, const double* vec) {
   hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, s, qp->K, qp->N, qp->D,
                      d.cell_ptr, d.coef, d.gval, d.G);
   FUSED_LAUNCHED(qp);
+  return SCP_OK;
+}
+
+// G = A_W^T g with g = (rho zc - yc) - rho A_W v (init) or rho A_W v, Q = S0 v: row values, then the per-cell gather
+int scp_qp_rows_gather(scp_qp* qp, bool init, const double* Q) {
+  const QpDev& d = qp->d;
+  hipStream_t s = qp->ctx->stream;
+  if (!qp->csr_valid) {
+    int rc = scp_qp_csr_build(qp);
+    if (rc) return rc;
+  }
+  const int64_t C = qp->C, nx = (int64_t)qp->K * C;
+  const double rho_c = qp->rho * qp->st.rho_col_scale;
+  const dim3 rgrid((unsigned)((qp->nW + 255) / 256)), rblock(256);
+#define SCP_ROWS_VALUE(DD, INIT)                                                                                        \
+  hipLaunchKernelGGL((rows_value_kernel<DD, INIT>), rgrid, rblock, 0, s, qp->nW, C, rho_c, d.w_k, d.w_i, d.w_j, d.w_eta, Q, \
+                     d.zc, d.yc, d.pos_i, d.pos_j, d.gval)
+  if (qp->D == 2) {
+    if (init) SCP_ROWS_VALUE(2, true);
+    else SCP_ROWS_VALUE(2, false);
+  } else {
+    if (init) SCP_ROWS_VALUE(3, true);
+    else SCP_ROWS_VALUE(3, false);
+  }
+#undef SCP_ROWS_VALUE
+  hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, s, qp->K, qp->N, qp->D,
+                     d.cell_ptr, d.coef, d.gval, d.G);
+  FUSED_LAUNCHED(qp);
+  qp->cg1_ready = false;  // gval is the single-step pipeline's carried row value too
   return SCP_OK;
 }
 

@@ -112,6 +112,8 @@ int scp_qp_qp0_iterations(scp_qp* qp, int nit, double* dy_out);
 // 2: g = vec[n].  Two launches, no atomics.
 int scp_qp_csr_scatter(scp_qp* qp, int mode, const double* vec);
 int scp_qp_csr_build(scp_qp* qp);
+// G = A_W^T g, g = (rho zc - yc) - rho A_W v (init) or rho A_W v with Q = S0 v: deterministic (gather over the incidence lists)
+int scp_qp_rows_gather(scp_qp* qp, bool init, const double* Q);
 int scp_qp_cg1_prepare(scp_qp* qp);
 constexpr int SCP_SYNC_WORDS = 16;  // u64: give-up word | scratch
 constexpr int SCP_GPART_WORDS = 2 * 256 * 4;  // two buffers x (at most one workgroup per CU) x two doubles as granule pairs

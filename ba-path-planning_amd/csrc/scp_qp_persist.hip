@@ -104,9 +104,15 @@ __device__ inline void ld_cell(const u64* g, u32x4 (&w)[D]) {  // the D doubles 
 __device__ inline bool pair_ok(const u32x4& w, unsigned tag) { return w[1] == tag && w[3] == tag; }
 __device__ inline double pair_value(const u32x4& w) { return __hiloint2double((int)w[2], (int)w[0]); }
 
+// Agents (= waves) per workgroup.  2-D: 8 waves, two per SIMD, 256 registers each (waves 4-7 double as the T r matrix-core
+// waves).  3-D: FOUR agents (12 of the 16 tile columns), not five -- a wave's 30 columns of fixed-row state need more than 256
+// registers, and with one wave per SIMD the whole 512-entry file is its own (five waves spilled 160 registers to scratch
+// inside the step loop: 12.9 us per step against 9.4 in 2-D).
+constexpr int persist_apb(int D) { return D == 3 ? 4 : CB / D; }
+
 template <int D>
-__global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs A) {
-  constexpr int APB = CB / D;    // agents = waves per workgroup
+__global__ __launch_bounds__(64 * persist_apb(D)) void cg1_persist_kernel(PersistArgs A) {
+  constexpr int APB = persist_apb(D);    // agents = waves per workgroup
   constexpr int NT = 64 * APB;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ double red[NCHK][APB];
@@ -709,7 +715,7 @@ __global__ __launch_bounds__(64 * (CB / D)) void cg1_persist_kernel(PersistArgs 
 }
 
 size_t persist_lds_bytes(int K, int D, int cap, int nblk) {
-  const int apb = CB / D;
+  const int apb = persist_apb(D);
   size_t dbl = (size_t)3 * CB * pad_col(K) + (size_t)apb * 64 * D + (size_t)NCHK * nblk + (size_t)cap * (4 * D + 4);
   size_t ints = (size_t)3 * cap + (size_t)apb * K + 1;
   return dbl * sizeof(double) + ((ints + 1) / 2 * 2) * sizeof(int);
@@ -721,7 +727,7 @@ size_t persist_lds_bytes(int K, int D, int cap, int nblk) {
 bool scp_qp_persist_eligible(const scp_qp* qp) {
   if (!qp->st.persistent || qp->st.cg_iters != 1 || qp->st.use_mfma != 1) return false;
   if (qp->K > 64 || qp->nW <= 0 || qp->persist_off) return false;
-  const int apb = CB / qp->D;
+  const int apb = persist_apb(qp->D);
   const int nblk = (qp->N + apb - 1) / apb;
   return nblk <= qp->ctx->n_cu;  // one workgroup per CU, all resident (grid-wide rendezvous)
 }
@@ -739,7 +745,7 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   const scp_qp_settings& st = qp->st;
   const int K = qp->K, D = qp->D;
   const int64_t C = qp->C, nx = (int64_t)K * C;
-  const int apb = CB / D;
+  const int apb = persist_apb(D);
   const int nblk = (qp->N + apb - 1) / apb;
   *ran = 0;
   if (!qp->cg1_ready) {
@@ -804,11 +810,11 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   if (D == 2) {
     if (lds > 64 * 1024)
       SCP_HIP_CHECK(ctx, scp_raise_lds_limit(ctx->device, reinterpret_cast<const void*>(cg1_persist_kernel<2>), lds));
-    hipLaunchKernelGGL(cg1_persist_kernel<2>, dim3(nblk), dim3(64 * (CB / 2)), lds, s, a);
+    hipLaunchKernelGGL(cg1_persist_kernel<2>, dim3(nblk), dim3(64 * persist_apb(2)), lds, s, a);
   } else {
     if (lds > 64 * 1024)
       SCP_HIP_CHECK(ctx, scp_raise_lds_limit(ctx->device, reinterpret_cast<const void*>(cg1_persist_kernel<3>), lds));
-    hipLaunchKernelGGL(cg1_persist_kernel<3>, dim3(nblk), dim3(64 * (CB / 3)), lds, s, a);
+    hipLaunchKernelGGL(cg1_persist_kernel<3>, dim3(nblk), dim3(64 * persist_apb(3)), lds, s, a);
   }
   SCP_HIP_CHECK(ctx, hipGetLastError());
   *ran = 1;

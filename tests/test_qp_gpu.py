@@ -97,6 +97,33 @@ def test_collision_qp_paths_and_pcg_steps(ctx, cg, use_mfma):
     qp.close()
 
 
+@pytest.mark.parametrize("cg,use_mfma", [(1, 1), (2, 1), (3, 2), (3, 0)])
+def test_every_qp_path_is_deterministic(ctx, cg, use_mfma):
+    """No atomics on floating-point data anywhere in the iteration: A_W^T g is a gather over sorted incidence lists on every
+    path (single-step, multi-step fused, generic MFMA / VALU), so two solves of the same QP agree bit for bit -- primal
+    and duals.  (Round 1 scattered with atomics on the cg_iters >= 2 and generic paths.)"""
+    import torch
+
+    prob = ref_problem(24, 5, 10.0, 0.2)
+    x0, _, _ = qo.admm_structured(prob, st=oracle_settings(eps_abs=1e-6, eps_rel=1e-6))
+    pos, _ = so.kinematics(prob, x0)
+    eta, l_col, dist = so.linearize_pairs(prob, pos)
+    W = np.nonzero(dist - prob.R < 0.5)[0]
+    assert len(W) > 100
+    runs = []
+    for _ in range(2):
+        qp = make_qp(ctx, prob, max_iter=10000, cg_iters=cg, use_mfma=use_mfma)
+        qp.reset(ctx.tensor(x0))
+        qp.add_rows(torch.as_tensor(W, dtype=torch.int64, device=ctx.tdev), ctx.tensor(eta[W]), ctx.tensor(l_col[W]))
+        info = qp.solve()
+        yf, yc = qp.duals()
+        runs.append((info["iter"], qp.solution().cpu().numpy(), yf.cpu().numpy(), yc.cpu().numpy()))
+        qp.close()
+    assert runs[0][0] == runs[1][0] and runs[0][0] >= 25
+    for a, b in zip(runs[0][1:], runs[1][1:]):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("n,seed,T,h,margin", [(4, 1, 10.0, 0.5, 0.5), (10, 7, 10.0, 0.2, 0.5), (4, 1, 10.0, 0.5, 1e9)])
 def test_collision_qp_matches_oracle(ctx, n, seed, T, h, margin):
     """First SCP iteration's joint QP, working set fixed by `margin` (1e9 = every collision row)."""

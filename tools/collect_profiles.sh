@@ -44,10 +44,16 @@ timeout -k 10 200 python3 tools/full_solve_timing.py 64 256 1024 4096 > $OUT/ful
 timeout -k 10 200 python3 tools/ref_config_timing.py > $OUT/ref_config_timing.txt 2>&1
 timeout -k 10 300 python3 tools/soak.py 80 > $OUT/soak_80.txt 2>&1; tail -1 $OUT/soak_80.txt
 timeout -k 10 300 python3 tools/soak.py 80 --polish > $OUT/soak_80_polish.txt 2>&1; tail -1 $OUT/soak_80_polish.txt
-for S in 1 4; do
-  timeout -k 10 250 python3 -m path_planning.cli.compute_trajectories_batch --Ns 128 --trials 96 --scenario grid-swap --seed 1 --results-dir /tmp/b$S --streams $S 2>&1 | grep "scenarios/s"
-done > $OUT/batch128.txt 2>&1
-cat $OUT/batch128.txt
-timeout -k 10 100 python3 -m path_planning.cli.compute_trajectories --seed 3 --no-plots > $OUT/demo_k500.txt 2>&1; tail -4 $OUT/demo_k500.txt
+# config 5's unit: 128-agent scenarios per second on this ONE GPU, processes x streams, steady state (--warmup 1), and the
+# cold figure (solver creation and kernel loading inside the clock) for one process
+TRIALS=256 bash tools/batch_rate.sh $OUT/batch128_rates.txt "1:1 1:4 2:4 4:4" > /dev/null 2>&1
+TRIALS=96 WARMUP=0 bash tools/batch_rate.sh $OUT/batch128_cold.txt "1:1 1:4" > /dev/null 2>&1
+cat $OUT/batch128_rates.txt $OUT/batch128_cold.txt
+cd /tmp
+timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_solve128 -- python3 $R/tools/solve128.py 128 8 > $OUT/solve128.log 2>&1
+cp $(find $OUT/prof_solve128 -name "*kernel_stats.csv" | head -1) $OUT/solve128_kernel_stats.csv 2>/dev/null
+grep "^solve" $OUT/solve128.log > $OUT/solve128.txt
+cd $R
+timeout -k 10 100 python3 tools/demo_k500.py > $OUT/demo_k500.txt 2>&1; tail -5 $OUT/demo_k500.txt
 timeout -k 10 60 tools/bin/grid_sync_bench 2000 > $OUT/grid_sync_bench.txt 2>&1
 echo "== done"

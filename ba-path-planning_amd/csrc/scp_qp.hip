@@ -426,17 +426,36 @@ __global__ __launch_bounds__(256) void qp_reset_kernel(int N, int K, int D, int 
     if (live) x[(int64_t)k * C + c] = v;
   }
   __syncthreads();
-  for (int r = rg; r < Rf + K; r += RG) {
-    const double* __restrict__ row = r < Rf ? F + (size_t)r * K : S0 + (size_t)(r - Rf) * K;
-    double acc = 0.0;
-    for (int k = 0; k < K; ++k) acc += row[k] * reset_xs[k * RESET_COLS + lc];
+  // four rows per thread and pass: one LDS read of x[k] feeds four independent multiply-add chains (one row at a time was
+  // a chain of K dependent loads + FMAs per row: 42 us at 1024 agents)
+  constexpr int RB = 4;
+  for (int r0 = rg * RB; r0 < Rf + K; r0 += RG * RB) {
+    const double* __restrict__ row[RB];
+    double acc[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int r = min(r0 + j, Rf + K - 1);
+      row[j] = r < Rf ? F + (size_t)r * K : S0 + (size_t)(r - Rf) * K;
+      acc[j] = 0.0;
+    }
+#pragma unroll 2
+    for (int k = 0; k < K; ++k) {
+      const double xv = reset_xs[k * RESET_COLS + lc];
+#pragma unroll
+      for (int j = 0; j < RB; ++j) acc[j] += row[j][k] * xv;
+    }
     if (!live) continue;
-    if (r < Rf) {
-      zf[(int64_t)r * C + c] = acc;
-      fx[(int64_t)r * C + c] = acc;
-      yf[(int64_t)r * C + c] = 0.0;
-    } else {
-      Qx[(int64_t)(r - Rf) * C + c] = acc;
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int r = r0 + j;
+      if (r >= Rf + K) break;
+      if (r < Rf) {
+        zf[(int64_t)r * C + c] = acc[j];
+        fx[(int64_t)r * C + c] = acc[j];
+        yf[(int64_t)r * C + c] = 0.0;
+      } else {
+        Qx[(int64_t)(r - Rf) * C + c] = acc[j];
+      }
     }
   }
 }
@@ -522,6 +541,7 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   const size_t ncell = (size_t)(C / D) * K;
   d.cell_ptr = c.take<int>(ncell + 1);
   d.cell_cur = c.take<int>(ncell);
+  d.scan_tot = c.take<int>(ncell / 4096 + 2);
   d.ent_code = c.take<int>((size_t)2 * cap);
   d.coef = c.take<double>((size_t)2 * cap * D);
   d.gval = c.take<double>((size_t)2 * cap);

@@ -1337,59 +1337,58 @@ __global__ __launch_bounds__(256) void csr_count_kernel(int64_t nW, int K, const
   atomicAdd(cnt + cell_of(wk[n], wj[n], K), 1);
 }
 
-// exclusive scan of cnt[0..ncell) into ptr (in place: cnt and ptr are the same array), cursors = ptr; one workgroup,
-// 4096 cells per pass (coalesced), the next pass's counts fetched before this pass's barriers, wave scans on DPP
+// exclusive scan of cnt[0..ncell) into ptr (in place: cnt and ptr are the same array), cursors = ptr.  Two launches that
+// fill the chip instead of one workgroup walking the array (67 us at N K = 51 200, a fortieth of the benchmark step):
+// (1) every workgroup scans its own 4096 cells and leaves their total, (2) every workgroup adds the totals before it.
 template <int CTRL, int ROW_MASK>
 __device__ inline int dpp_mov0_i32(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true);
 }
-__global__ __launch_bounds__(1024) void csr_scan_kernel(int ncell, int* __restrict__ ptr, int* __restrict__ cur) {
-  // SC consecutive cells per thread and pass (16 384 cells per pass: 51 200 cells in 4 passes; a pass costs one
-  // memory round trip + two barriers whatever its width -- 4 cells per thread took 38 us at N K = 51 200)
-  constexpr int SC = 16;
-  __shared__ int wsum[16];
-  __shared__ int carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
+constexpr int SCAN_SC = 16;                 // consecutive cells per thread
+constexpr int SCAN_CELLS = 256 * SCAN_SC;   // per workgroup
+__global__ __launch_bounds__(256) void csr_scan_local_kernel(int ncell, int* __restrict__ ptr, int* __restrict__ blk_tot) {
+  __shared__ int wsum[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  auto loadn = [&](int c, int (&v)[SC]) {
+  const int c = blockIdx.x * SCAN_CELLS + SCAN_SC * (int)threadIdx.x;
+  int v[SCAN_SC], tot = 0;
 #pragma unroll
-    for (int e = 0; e < SC; ++e) v[e] = c + e < ncell ? ptr[c + e] : 0;
-  };
-  int v[SC], vn[SC];
-  loadn(SC * (int)threadIdx.x, v);
-  for (int b0 = 0; b0 < ncell; b0 += SC * 1024) {
-    const int c = b0 + SC * (int)threadIdx.x;
-    loadn(c + SC * 1024, vn);  // (cells of a later pass: not written yet)
-    int tot = 0;
-#pragma unroll
-    for (int e = 0; e < SC; ++e) tot += v[e];
-    int incl = tot;
-    incl += dpp_mov0_i32<0x111, 0xF>(incl);
-    incl += dpp_mov0_i32<0x112, 0xF>(incl);
-    incl += dpp_mov0_i32<0x114, 0xF>(incl);
-    incl += dpp_mov0_i32<0x118, 0xF>(incl);
-    incl += dpp_mov0_i32<0x142, 0xA>(incl);
-    incl += dpp_mov0_i32<0x143, 0xC>(incl);
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int base = carry_s;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-    int run = base + incl - tot;
-#pragma unroll
-    for (int e = 0; e < SC; ++e) {
-      if (c + e < ncell) {
-        ptr[c + e] = run;
-        cur[c + e] = run;
-      }
-      run += v[e];
-    }
-    __syncthreads();
-    if (threadIdx.x == 1023) carry_s = base + incl;
-#pragma unroll
-    for (int e = 0; e < SC; ++e) v[e] = vn[e];
+  for (int e = 0; e < SCAN_SC; ++e) {
+    v[e] = c + e < ncell ? ptr[c + e] : 0;
+    tot += v[e];
   }
+  int incl = tot;
+  incl += dpp_mov0_i32<0x111, 0xF>(incl);
+  incl += dpp_mov0_i32<0x112, 0xF>(incl);
+  incl += dpp_mov0_i32<0x114, 0xF>(incl);
+  incl += dpp_mov0_i32<0x118, 0xF>(incl);
+  incl += dpp_mov0_i32<0x142, 0xA>(incl);
+  incl += dpp_mov0_i32<0x143, 0xC>(incl);
+  if (lane == 63) wsum[wave] = incl;
   __syncthreads();
-  if (threadIdx.x == 0) ptr[ncell] = carry_s;
+  int run = incl - tot;
+  for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+  for (int e = 0; e < SCAN_SC; ++e) {
+    if (c + e < ncell) ptr[c + e] = run;
+    run += v[e];
+  }
+  if (threadIdx.x == 255) blk_tot[blockIdx.x] = run;
+}
+
+__global__ __launch_bounds__(256) void csr_scan_add_kernel(int ncell, int nblk, int* __restrict__ ptr, int* __restrict__ cur,
+                                                            const int* __restrict__ blk_tot) {
+  int off = 0;
+  for (int b = 0; b < (int)blockIdx.x; ++b) off += blk_tot[b];  // (wave-uniform: scalar loads)
+  const int c = blockIdx.x * SCAN_CELLS + SCAN_SC * (int)threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < SCAN_SC; ++e) {
+    if (c + e < ncell) {
+      const int v = ptr[c + e] + off;
+      ptr[c + e] = v;
+      cur[c + e] = v;
+    }
+  }
+  if (blockIdx.x == nblk - 1 && threadIdx.x == 0) ptr[ncell] = off + blk_tot[nblk - 1];
 }
 
 __global__ __launch_bounds__(256) void csr_fill_kernel(int64_t nW, int K, const int* __restrict__ wk,
@@ -1561,7 +1560,9 @@ int scp_qp_csr_build(scp_qp* qp) {
   if (qp->nW > 0) {
     const dim3 rgrid((unsigned)((qp->nW + 255) / 256));
     hipLaunchKernelGGL(csr_count_kernel, rgrid, dim3(256), 0, s, qp->nW, qp->K, d.w_k, d.w_i, d.w_j, d.cell_ptr);
-    hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, ncell, d.cell_ptr, d.cell_cur);
+    const int sblk = (ncell + SCAN_CELLS - 1) / SCAN_CELLS;
+    hipLaunchKernelGGL(csr_scan_local_kernel, dim3(sblk), dim3(256), 0, s, ncell, d.cell_ptr, d.scan_tot);
+    hipLaunchKernelGGL(csr_scan_add_kernel, dim3(sblk), dim3(256), 0, s, ncell, sblk, d.cell_ptr, d.cell_cur, d.scan_tot);
     hipLaunchKernelGGL(csr_fill_kernel, rgrid, dim3(256), 0, s, qp->nW, qp->K, d.w_k, d.w_i, d.w_j, d.cell_cur, d.ent_code);
     hipLaunchKernelGGL(csr_sort_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, ncell, d.cell_ptr, d.ent_code);
     hipLaunchKernelGGL(csr_finish_kernel, dim3((unsigned)((2 * qp->nW + 255) / 256)), dim3(256), 0, s, 2 * qp->nW, qp->D,

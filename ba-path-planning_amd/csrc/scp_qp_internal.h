@@ -43,6 +43,7 @@ struct QpDev {
   // deterministic row -> column transfer (single-step pipeline): incidence lists per (time step, agent) cell
   int* cell_ptr;  // [N*K + 1] exclusive offsets into the entry arrays
   int* cell_cur;  // [N*K]     fill cursors (build time)
+  int* scan_tot;  // [N*K / 4096 + 2] per-workgroup totals of the offset scan
   int* ent_code;  // [2 cap]   2 n + side, sorted inside every cell (side 0: agent i, +eta; side 1: agent j, -eta)
   double* coef;   // [2 cap][D] signed eta of the entry
   double* gval;   // [2 cap]   per-entry row value, written by the row kernels (no atomics)

@@ -158,7 +158,7 @@ def main():
 
     # HBM traffic of that kernel from the committed PMC passes (profiles/README.md): same workload only, and only while
     # the kernel source is the one the counters were collected on (otherwise null: a stale figure helps nobody)
-    traffic, traffic_note = None, None
+    traffic, traffic_note, viol_traffic = None, None, None
     tpath = os.path.join(ROOT, "profiles", "r02_pairwise_traffic.json")
     if world == 1 and (N, K, D) == (1024, 50, 2) and os.path.exists(tpath):
         import hashlib
@@ -169,6 +169,7 @@ def main():
         sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
         if tj.get("kernel_source_sha256") == sha:
             traffic = tj["linearize"]["hbm_bytes"]
+            viol_traffic = tj.get("violations_recompute", {}).get("hbm_bytes")
         else:
             traffic_note = "scp_kernels.hip changed since the PMC passes were collected: re-run tools/collect_profiles.sh"
 
@@ -206,6 +207,13 @@ def main():
             # bound), and the joint QP is a chain of ~500 dependent ADMM steps whose whole state (14 MB) stays on chip:
             # latency bound by construction, so the step as a whole sits at a percent of the HBM roofline
             "violations_pass_avg_ms": float(np.mean(viol_ms)) if viol_ms else None,
+            "violations_pass": {
+                "kernel": "pair_pass_kernel<D,VIOL_RECOMPUTE> (scp_collision_violations_at)",
+                "bound": "fp64 VALU / LDS (eta, R - dist recomputed from the LDS-resident linearisation point: no row stream)",
+                "avg_launch_ms": float(np.mean(viol_ms)) if viol_ms else None,
+                "rows_per_launch": rows, "traffic": viol_traffic,
+                "rows_per_s": rows / (float(np.mean(viol_ms)) * 1e-3) if viol_ms else None,
+            },
             "admm": {"iterations": int(infos[-1]["iter"]), "solve_ms": float(infos[-1]["solve_ms"]),
                      "us_per_iteration": float(infos[-1]["solve_ms"]) * 1e3 / max(int(infos[-1]["iter"]), 1),
                      "note": "device time of the QP solve (HIP events) / ADMM iterations: persistent kernel, two "

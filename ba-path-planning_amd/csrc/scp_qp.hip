@@ -859,13 +859,13 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
   qp->persist_cap_nW = -1;
   qp->persist_cap = 0;
   qp->persist_epoch = 0;
-  if (hipHostMalloc(&qp->h_scal, (SL_COUNT + SCP_RESID_CAP + 2) * sizeof(double),
+  if (hipHostMalloc(&qp->h_scal, (SL_COUNT + SCP_RESID_CAP + 4) * sizeof(double),
                     hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer((void**)&qp->h_scal_dev, qp->h_scal, 0) != hipSuccess) {
     delete qp;
     return scp_fail(ctx, SCP_ERR_HIP, "qp_create: hipHostMalloc failed");
   }
-  memset(qp->h_scal, 0, (SL_COUNT + SCP_RESID_CAP + 2) * sizeof(double));  // incl. the completion flag
+  memset(qp->h_scal, 0, (SL_COUNT + SCP_RESID_CAP + 4) * sizeof(double));  // incl. the completion flag
   qp->h_persist = (unsigned*)(qp->h_scal + SL_COUNT + SCP_RESID_CAP + 1);  // status word of the persistent kernel
   qp->h_persist_dev = (unsigned*)(qp->h_scal_dev + SL_COUNT + SCP_RESID_CAP + 1);
   // constant blocks (scp.py:10-28, :198-203, :227-232, :489-491), built on the host once per (K, h)
@@ -1052,6 +1052,13 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
         it = it_done;
         qp->qx_fresh = true;  // the kernel's last check left F x and S0 x exact
         persist_done = true;
+        if (qp->persist_rho_switches > 0) {
+          // adaptive-rho updates whose blocks were cached happened inside the kernel (same test, same values as below):
+          // adopt the result; build_kkt finds the slot and points d.* at it
+          qp->rho = qp->persist_rho;
+          info->rho_updates += qp->persist_rho_switches;
+          QP_CHECK(build_kkt(qp));
+        }
       }
     }
     int n_it = 1;

@@ -91,7 +91,9 @@ struct scp_qp {
   int64_t persist_cap_nW;            // working-set size that overflowed the LDS entry tables (-1: none): not tried again
   int persist_cap;                   // LDS entry capacity per workgroup (all the LDS that is left)
   unsigned long long persist_epoch;  // ADMM steps run by persistent launches so far: the step tags of the granules never repeat
-  unsigned* h_persist;               // mapped host words written by the kernel: [0] exit code, [1] iterations done
+  unsigned* h_persist;               // mapped host words written by the kernel: [0] exit code, [1] iterations done, [2] rho switches
+  int persist_rho_switches;          // of the latest persistent launch: adaptive-rho updates the kernel made by itself ...
+  double persist_rho;                // ... and the rho it ended with
   unsigned* h_persist_dev;
 };
 

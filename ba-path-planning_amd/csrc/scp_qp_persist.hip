@@ -68,6 +68,17 @@ struct PersistArgs {
   u64* host_flag;         // mapped completion word, set to `seq` last
   u64 seq;
   unsigned epoch0;        // steps completed by earlier launches (tags never repeat; the buffers start zeroed)
+  // adaptive rho inside the kernel: the rho values whose blocks the host has cached (scp_qp::kkt).  When a check asks for a
+  // new rho that is in this table the kernel switches by itself (operands reloaded, row values recomputed) and goes on;
+  // otherwise it returns EXIT_RHO and the host builds the blocks.  host_status[2] = switches made, *host_rho = rho at exit.
+  double rho_col_scale;
+  double* host_rho;
+  int n_tab;
+  struct RhoSlot {
+    double rho;
+    const double* pMinv;
+    const double* pT;
+  } tab[SCP_KKT_SLOTS_MAX];
 };
 
 // why the kernel returned (host_status[0]); the host re-derives every decision from the nine check results
@@ -145,7 +156,9 @@ __global__ __launch_bounds__(64 * persist_apb(D)) void cg1_persist_kernel(Persis
   const bool aok = agent < N;
   const int k = lane;
   const bool live = aok && k < K;
-  const double h = A.h, hh = h * h, rho = A.rho, rho_c = A.rho_c, alpha = A.alpha;
+  const double h = A.h, hh = h * h, alpha = A.alpha;
+  double rho = A.rho, rho_c = A.rho_c;  // (an in-kernel rho switch changes them)
+  unsigned n_rho = 0;
   const int tK = (K + 15) >> 4, nks = (K + 3) >> 2;
   const int nblk = A.nblk;
 
@@ -649,11 +662,36 @@ __global__ __launch_bounds__(64 * persist_apb(D)) void cg1_persist_kernel(Persis
     if (with_dy && chk[CK_NDY] > A.eps_prim_inf && chk[CK_SUPP] < -A.eps_prim_inf * chk[CK_NDY] &&
         chk[CK_NATDY] < A.eps_prim_inf * chk[CK_NDY]) { exit_code = EXIT_INFEASIBLE; break; }
     if (A.rho_tol > 0.0 && it_done % A.rho_interval == 0) {
-      // rho estimate as the host computes it, BEFORE its snap to the 2^(1/4) grid (which moves it by at most 2^(1/8)):
-      // leave whenever the snapped value could cross the update threshold and let the host decide exactly
+      // OSQP's rho estimate, snapped to the 2^(1/4) grid as the host does it (scp_qp_solve).  Device log2 / exp2 may differ
+      // from the host's in the last bit, so the candidate only SELECTS: the value that counts is the host-computed double
+      // in the table of cached rho, and the threshold test is repeated on it exactly as the host would.
       const double prim = chk[CK_RP] / fmax(np_, 1e-10), dual = chk[CK_RD] / fmax(nd_, 1e-10);
       const double nr = fmin(fmax(rho * sqrt(prim / fmax(dual, 1e-10)), 1e-6), 1e6);
-      if (nr * 1.0906 > rho * A.rho_tol || nr < 1.0906 * rho / A.rho_tol) { exit_code = EXIT_RHO; break; }
+      const double cand = exp2(round(4.0 * log2(nr)) * 0.25);
+      if (cand > rho * A.rho_tol * (1.0 - 1e-9) || cand < rho / A.rho_tol * (1.0 + 1e-9)) {  // (else: clearly no update)
+        int slot = -1;
+        for (int i = 0; i < A.n_tab; ++i)
+          if (fabs(A.tab[i].rho - cand) <= 1e-12 * cand) slot = i;
+        if (slot < 0) { exit_code = EXIT_RHO; break; }  // not cached yet: the host builds the blocks and relaunches
+        const double nrs = A.tab[slot].rho;
+        if (nrs > rho * A.rho_tol || nrs < rho / A.rho_tol) {
+          // ---- switch rho in place (what the host does between two launches: build_kkt hit + rows_value_kernel) -------------
+          rho = nrs;
+          rho_c = rho * A.rho_col_scale;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) rr[t] = (t >= 2 && k == K - 1) ? rho * A.rho_eq : rho;
+          tile_prefetch<CHB>(use_T && wave >= tK ? A.tab[slot].pT : A.tab[slot].pMinv, nks,
+                             wave < tK ? wave : (use_T && wave < 2 * tK ? wave - tK : 0), 0, nks, aM);
+          for (int e = threadIdx.x; e < ne; e += NT) {  // row values of the next right-hand side from the exact S0 x cells
+            double ax = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) ax += e_c[(size_t)e * D + d] * (e_qo[(size_t)e * D + d] - e_qp[(size_t)e * D + d]);
+            e_g[e] = (rho_c * e_z[e] - e_y[e]) - rho_c * ax;
+          }
+          __syncthreads();
+          ++n_rho;
+        }
+      }
     }
   }
   }  // batches
@@ -709,6 +747,8 @@ __global__ __launch_bounds__(64 * persist_apb(D)) void cg1_persist_kernel(Persis
     for (int j = 0; j < NCHK; ++j)
       __hip_atomic_store((u64*)(A.host_scal + slot[j]), (u64)__double_as_longlong(chk[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(A.host_status + 1, (unsigned)it_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(A.host_status + 2, n_rho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store((u64*)A.host_rho, (u64)__double_as_longlong(rho), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(A.host_status, exit_code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(A.host_flag, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -794,9 +834,21 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   a.host_status = qp->h_persist_dev;
   a.host_scal = qp->h_scal_dev;
   a.host_flag = (u64*)(qp->h_scal_dev + SL_COUNT + SCP_RESID_CAP);
+  a.host_rho = qp->h_scal_dev + SL_COUNT + SCP_RESID_CAP + 3;
+  a.rho_col_scale = st.rho_col_scale;
+  a.n_tab = 0;
+  for (int i = 0; i < qp->n_kkt; ++i)  // every rho whose blocks are resident (same sigma)
+    if (qp->kkt[i].used && qp->kkt[i].sigma == st.sigma) {
+      a.tab[a.n_tab].rho = qp->kkt[i].rho;
+      a.tab[a.n_tab].pMinv = qp->kkt[i].pMinv;
+      a.tab[a.n_tab].pT = qp->kkt[i].pT;
+      ++a.n_tab;
+    }
   a.seq = ++qp->check_seq;
   qp->h_persist[0] = 0u;
   qp->h_persist[1] = (unsigned)it0;
+  qp->h_persist[2] = 0u;
+  qp->persist_rho_switches = 0;
   if (qp->persist_epoch == 0 || qp->persist_epoch + (u64)budget >= 0x7FFFFFF0ull) {
     // first launch, the one after a give-up, or the step tags would reach bit 31 (reserved for the checks): every polled
     // word starts from zero
@@ -831,7 +883,12 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
     *ran = 0;
     return SCP_OK;
   }
-  if (*code != SCP_PERSIST_GAVE_UP) qp->persist_epoch += (u64)(*it_done - it0);  // one tag per ADMM step
+  if (*code != SCP_PERSIST_GAVE_UP) {
+    qp->persist_epoch += (u64)(*it_done - it0);  // one tag per ADMM step
+    // rho switches the kernel made by itself (scp_qp_solve adopts the value and points d.* at that slot)
+    qp->persist_rho_switches = (int)((volatile unsigned*)qp->h_persist)[2];
+    qp->persist_rho = ((volatile double*)qp->h_scal)[SL_COUNT + SCP_RESID_CAP + 3];
+  }
   return SCP_OK;
 }
 

@@ -124,6 +124,37 @@ def test_every_qp_path_is_deterministic(ctx, cg, use_mfma):
         np.testing.assert_array_equal(a, b)
 
 
+def test_in_kernel_rho_switch_equals_host_path(ctx):
+    """Adaptive rho: the first solve of a QP object finds no cached blocks for the new rho values, so the persistent kernel
+    returns and the host builds them (build_kkt + rows_value_kernel); a second solve of the SAME problem on the same object
+    finds them cached and the kernel switches by itself (operands reloaded, row values recomputed in LDS).  Same
+    iterates bit for bit, same number of rho updates, and the oracle's count."""
+    import torch
+
+    prob = ref_problem(18, 1, 10.0, 0.2)  # two rho updates in 250 ADMM steps
+    x0, _, _ = qo.admm_structured(prob, st=oracle_settings(eps_abs=1e-6, eps_rel=1e-6))
+    pos, _ = so.kinematics(prob, x0)
+    eta, l_col, dist = so.linearize_pairs(prob, pos)
+    W = np.nonzero(dist - prob.R < 0.5)[0]
+    st = oracle_settings(max_iter=10000, max_rounds=1, cg_iters=1, eps_abs=1e-5, eps_rel=1e-5)
+    _, _, io = qo.admm_structured(prob, eta, l_col, dist, x0=x0, st=st, rows0=W)
+    assert io["rho_updates"] == 2 and io["status_val"] == 1
+    qp = make_qp(ctx, prob, max_iter=10000, cg_iters=1, eps_abs=1e-5, eps_rel=1e-5)
+    runs = []
+    for _ in range(3):
+        qp.reset(ctx.tensor(x0))
+        qp.add_rows(torch.as_tensor(W, dtype=torch.int64, device=ctx.tdev), ctx.tensor(eta[W]), ctx.tensor(l_col[W]))
+        info = qp.solve()
+        yf, yc = qp.duals()
+        runs.append((info["iter"], info["rho_updates"], info["status_val"], qp.solution().cpu().numpy(), yf.cpu().numpy(),
+                     yc.cpu().numpy()))
+    qp.close()
+    assert runs[0][:3] == runs[1][:3] == runs[2][:3] == (io["iter"], io["rho_updates"], 1)
+    for r in runs[1:]:
+        for a, b in zip(runs[0][3:], r[3:]):
+            np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("n,seed,T,h,margin", [(4, 1, 10.0, 0.5, 0.5), (10, 7, 10.0, 0.2, 0.5), (4, 1, 10.0, 0.5, 1e9)])
 def test_collision_qp_matches_oracle(ctx, n, seed, T, h, margin):
     """First SCP iteration's joint QP, working set fixed by `margin` (1e9 = every collision row)."""

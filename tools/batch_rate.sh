@@ -12,11 +12,11 @@ for PS in $COMBOS; do
   echo "procs $P streams $S" >> $OUT
   if [ "$P" = "1" ]; then
     timeout -k 10 250 python3 -m path_planning.cli.compute_trajectories_batch --Ns 128 --trials $TRIALS --scenario grid-swap --seed 1 \
-      --results-dir /tmp/b_${P}_${S} --streams $S --warmup ${WARMUP:-1} 2>&1 | grep "scenarios/s" >> $OUT
+      --results-dir /tmp/b_${P}_${S} --streams $S --warmup ${WARMUP:-1} 2>&1 | grep "scenarios/s\|errors=" >> $OUT
   else
     timeout -k 10 250 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $P --master-addr 127.0.0.1 \
       --master-port $((29600 + P * 10 + S)) -m path_planning.cli.compute_trajectories_batch --Ns 128 --trials $((TRIALS * P)) \
-      --scenario grid-swap --seed 1 --results-dir /tmp/b_${P}_${S} --streams $S --warmup ${WARMUP:-1} 2>&1 | grep "scenarios/s" >> $OUT
+      --scenario grid-swap --seed 1 --results-dir /tmp/b_${P}_${S} --streams $S --warmup ${WARMUP:-1} 2>&1 | grep "scenarios/s\|errors=" >> $OUT
   fi
 done
 cat $OUT

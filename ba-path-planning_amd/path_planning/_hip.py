@@ -101,6 +101,8 @@ class QpInfo(C.Structure):
         return d
 
 
+ABI_VERSION = 3  # SCP_ABI_VERSION of include/scp_hip.h this binding matches (checked when the library is loaded)
+
 EXPORTS = [
     "scp_set_host_wait", "scp_abi_version", "scp_ctx_create", "scp_ctx_destroy", "scp_last_error", "scp_ctx_synchronize",
     "scp_ctx_last_pair_ms",
@@ -135,6 +137,10 @@ def load_library():
     vp, i32, i64, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
     pd = C.POINTER(C.c_double)
     lib.scp_abi_version.restype = i32
+    if lib.scp_abi_version() != ABI_VERSION:  # a stale build: struct layouts and entry points may not match this binding
+        raise HipError(-4,  # SCP_ERR_STATE
+                       f"{path}: ABI version {lib.scp_abi_version()}, this binding needs {ABI_VERSION} -- rebuild "
+                       "(python -c 'import __graft_entry__ as g; g.build()')")
     lib.scp_set_host_wait.argtypes = [i32]
     lib.scp_set_host_wait.restype = None
     lib.scp_ctx_create.argtypes = [i32, vp, C.POINTER(vp)]

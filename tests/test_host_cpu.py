@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_hip.EXPORTS), declared ^ set(_hip.EXPORTS)
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert lib.scp_abi_version() == 3
+    assert lib.scp_abi_version() == _hip.ABI_VERSION == int(re.search(r"#define SCP_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
     # struct layouts agree with the header
     import subprocess
     import tempfile
@@ -192,3 +192,12 @@ def test_structured_vs_explicit_collision_qp():
     assert r["status_val"] == 1
     np.testing.assert_allclose(xs.ravel(), r["x"], rtol=0, atol=1e-6)
     assert np.all(A @ xs.ravel() >= np.hstack([lf, l_col]) - 1e-6)
+
+
+def test_graft_entry_build_runs_on_cpu():
+    """The driver's "does it build" check: __graft_entry__.build() compiles libscp_hip.so for gfx950 and the oracle's C
+    restatement (incremental: a no-op after the first build), imports the package and checks exports + ABI version."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+
+    g.build()

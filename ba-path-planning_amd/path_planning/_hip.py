@@ -511,7 +511,8 @@ class NativeSolver:
     def solve(self, limits, space, p0, v0, pf, vf, options: SolveOptions):
         """-> (acc, pos, vel device tensors (N, K, D), SolveResult, [QpRecord ...])"""
         c = self.ctx
-        acc, pos, vel = c.empty(self.N, self.K, self.D), c.empty(self.N, self.K, self.D), c.empty(self.N, self.K, self.D)
+        out = c.empty(3, self.N, self.K, self.D)  # one buffer: the caller fetches all three arrays with ONE copy (out._base)
+        acc, pos, vel = out[0], out[1], out[2]
         la, lp = _harr(limits)
         sa, sp = _harr(space)
         res = SolveResult()

@@ -334,10 +334,12 @@ class SCP:
             self.last_info["polish"] = dict(r.as_dict(), time_sec=float(r.time_sec))
         if its:
             self._last_qp_info = its[-1]
+        # acc, pos, vel are the three slices of one device buffer: one device-to-host copy for all of them
+        host = acc._base.cpu().numpy() if acc._base is not None else None
         self.trajectories = {
-            "positions": pos.cpu().numpy(),  # Shape (N, K, D)
-            "velocities": vel.cpu().numpy(),
-            "accelerations": acc.cpu().numpy(),
+            "positions": host[1] if host is not None else pos.cpu().numpy(),  # Shape (N, K, D)
+            "velocities": host[2] if host is not None else vel.cpu().numpy(),
+            "accelerations": host[0] if host is not None else acc.cpu().numpy(),
         }
         self._print(f"Trajectory generation completed in {time.time() - start_time:.3f} seconds")
         return self.trajectories

@@ -21,8 +21,8 @@ struct scp_ctx {
   hipStream_t stream;
   char err[512];
   // small device scratch for reductions / host read-back
-  double* d_scratch;      // 64 doubles
-  double* h_scratch;      // pinned, 64 doubles
+  double* d_scratch;      // 72 doubles
+  double* h_scratch;      // pinned, 72 doubles
   double* h_scratch_dev;  // its device address (kernels that hand a few numbers to the host write there directly)
   hipEvent_t ev0, ev1;
   hipEvent_t pair_ev0, pair_ev1;  // bracket the most recent pairwise kernel (scp_ctx_last_pair_ms)
@@ -36,6 +36,7 @@ struct scp_ctx {
   scp_stats_mirror* h_mirror;  // mapped host memory and its device address
   scp_stats_mirror* d_mirror;
   unsigned long long mirror_seq;  // sequence number of the latest compaction launch
+  unsigned long long rel_seq;     // of the latest scp_rel_step (completion word: h_scratch[64]; partials: h_scratch[0..64))
 };
 
 static inline int scp_fail(scp_ctx* ctx, int code, const char* fmt, ...) {

@@ -29,8 +29,10 @@ extern "C" int scp_ctx_create(int device, void* hip_stream, scp_ctx** out) {
   ctx->device = device;
   ctx->stream = (hipStream_t)hip_stream;
   if (hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ctx->n_cu = 0;
-  if (hipMalloc(&ctx->d_scratch, 64 * sizeof(double)) != hipSuccess ||
-      hipHostMalloc(&ctx->h_scratch, 64 * sizeof(double)) != hipSuccess ||
+  if (hipMalloc(&ctx->d_scratch, 72 * sizeof(double)) != hipSuccess ||
+      hipMemset(ctx->d_scratch, 0, 72 * sizeof(double)) != hipSuccess ||  // ([64]: ticket counter of scp_rel_step)
+      hipHostMalloc(&ctx->h_scratch, 72 * sizeof(double)) != hipSuccess ||
+      memset(ctx->h_scratch, 0, 72 * sizeof(double)) == nullptr ||        // ([64]: its completion word)
       hipHostGetDevicePointer((void**)&ctx->h_scratch_dev, ctx->h_scratch, 0) != hipSuccess ||
       hipHostMalloc(&ctx->h_mirror, sizeof(scp_stats_mirror)) != hipSuccess ||
       hipHostGetDevicePointer((void**)&ctx->d_mirror, ctx->h_mirror, 0) != hipSuccess ||
@@ -1010,12 +1012,22 @@ __global__ __launch_bounds__(CMP_THREADS) void compact_write_kernel(uint32_t* __
       if (!overflow) merge_into[w0 + i] |= m;
       map[w0 + i] = 0u;
     }
-    while (m) {
-      const int bit = __ffs((int)m) - 1;
-      m &= m - 1;
-      const int64_t lr = (w0 + i) * 32 + bit;
-      if (!overflow && slot < cap) rows[slot] = (lr / nq) * pairs + q_begin + (lr % nq);
-      ++slot;
+    if (m) {
+      // local row lr = 32 (w0 + i) + bit -> global id (lr / nq) pairs + q_begin + lr % nq with ONE 64-bit division per
+      // word (its bits belong to at most two time steps when nq >= 32; the inner loop covers tiny pair ranges)
+      const int64_t base = (w0 + i) * 32;
+      const int64_t kk = base / nq, rr = base - kk * nq;
+      while (m) {
+        const int bit = __ffs((int)m) - 1;
+        m &= m - 1;
+        int64_t k2 = kk, r2 = rr + bit;
+        while (r2 >= nq) {
+          r2 -= nq;
+          ++k2;
+        }
+        if (!overflow && slot < cap) rows[slot] = k2 * pairs + q_begin + r2;
+        ++slot;
+      }
     }
   }
 }
@@ -1087,12 +1099,22 @@ __global__ __launch_bounds__(CMP1_THREADS) void compact_small_kernel(uint32_t* _
         if (!overflow) merge_into[w0 + i] |= m;
         map[w0 + i] = 0u;
       }
-      while (m) {
-        const int bit = __ffs((int)m) - 1;
-        m &= m - 1;
-        const int64_t lr = (w0 + i) * 32 + bit;
-        if (!overflow && slot < cap) rows[slot] = (lr / nq) * pairs + q_begin + (lr % nq);
-        ++slot;
+      if (m) {
+        // local row lr = 32 (w0 + i) + bit -> global id (lr / nq) pairs + q_begin + lr % nq with ONE 64-bit division per
+        // word (its bits belong to at most two time steps when nq >= 32; the inner loop covers tiny pair ranges)
+        const int64_t base = (w0 + i) * 32;
+        const int64_t kk = base / nq, rr = base - kk * nq;
+        while (m) {
+          const int bit = __ffs((int)m) - 1;
+          m &= m - 1;
+          int64_t k2 = kk, r2 = rr + bit;
+          while (r2 >= nq) {
+            r2 -= nq;
+            ++k2;
+          }
+          if (!overflow && slot < cap) rows[slot] = k2 * pairs + q_begin + r2;
+          ++slot;
+        }
       }
     }
   }
@@ -1284,9 +1306,15 @@ extern "C" int scp_gather_rows(scp_ctx* ctx, int N, int K, int D, int64_t q_begi
 // ----------------------------------------------------------------------------------------------------
 // a1: relative step (scp.py:157-159)
 // ----------------------------------------------------------------------------------------------------
+// partial[2 b], partial[2 b + 1] = block b's sums; the partials live in mapped host memory and the LAST block to finish
+// (a ticket counter in device memory, at most 32 tickets) raises the completion word, so the host needs neither a copy
+// launch nor a stream drain to read them.
 __global__ __launch_bounds__(256) void rel_step_partial_kernel(int64_t n, const double* __restrict__ a,
                                                                 const double* __restrict__ b,
-                                                                double* __restrict__ partial) {
+                                                                double* __restrict__ partial,
+                                                                unsigned* __restrict__ ticket,
+                                                                unsigned long long* __restrict__ done,
+                                                                unsigned long long seq) {
   __shared__ double s0[4], s1[4];
   double d2 = 0.0, b2 = 0.0;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
@@ -1305,8 +1333,17 @@ __global__ __launch_bounds__(256) void rel_step_partial_kernel(int64_t n, const 
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    partial[2 * blockIdx.x] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
-    partial[2 * blockIdx.x + 1] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+    __hip_atomic_store((unsigned long long*)&partial[2 * blockIdx.x],
+                       (unsigned long long)__double_as_longlong((s0[0] + s0[1]) + (s0[2] + s0[3])), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store((unsigned long long*)&partial[2 * blockIdx.x + 1],
+                       (unsigned long long)__double_as_longlong((s1[0] + s1[1]) + (s1[2] + s1[3])), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+      *ticket = 0u;  // (the next launch on this stream starts after this kernel has ended)
+      __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -1315,10 +1352,15 @@ extern "C" int scp_rel_step(scp_ctx* ctx, int64_t n, const double* a_new, const 
   SCP_REQUIRE(ctx, n > 0 && a_new && a_prev && out, "rel_step: bad arguments");
   const int blocks = (int)((n + 256 * 8 - 1) / (256 * 8)) < 32 ? (int)((n + 256 * 8 - 1) / (256 * 8)) : 32;
   // the (at most 64) partial sums go straight to the mapped host scratch: no copy launch
+  const unsigned long long seq = ++ctx->rel_seq;
   hipLaunchKernelGGL(rel_step_partial_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, a_new, a_prev,
-                     ctx->h_scratch_dev);
+                     ctx->h_scratch_dev, (unsigned*)(ctx->d_scratch + 64), (unsigned long long*)(ctx->h_scratch_dev + 64), seq);
   SCP_HIP_CHECK(ctx, hipGetLastError());
-  SCP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  {
+    volatile unsigned long long* flag = (volatile unsigned long long*)(ctx->h_scratch + 64);
+    if (!scp_wait_host_word(flag, seq, 30)) SCP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // a fault surfaces here
+    if (*flag != seq) return scp_fail(ctx, SCP_ERR_HIP, "rel_step: completion word not written");
+  }
   double d2 = 0.0, b2 = 0.0;
   for (int b = 0; b < blocks; ++b) {
     d2 += ctx->h_scratch[2 * b];

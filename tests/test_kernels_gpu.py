@@ -98,7 +98,8 @@ def test_linearize_vs_reference(ctx, golden_dir, name):
 
 
 @pytest.mark.parametrize("N,K,D,seed", [(2, 5, 2, 1), (7, 13, 2, 2), (33, 21, 3, 3), (96, 50, 2, 4), (65, 50, 3, 5),
-                                        (130, 17, 2, 6), (300, 7, 2, 7), (257, 5, 3, 8), (256, 4, 2, 9)])
+                                        (130, 17, 2, 6), (300, 7, 2, 7), (257, 5, 3, 8), (256, 4, 2, 9),
+                                        (700, 10, 2, 10)])  # 2.4 M rows: the three-launch compaction (maps beyond 64 K words)
 def test_linearize_vs_oracle_synthetic(ctx, N, K, D, seed):
     from path_planning import _hip
 
@@ -163,7 +164,8 @@ def test_degenerate_pair(ctx):
 
 
 @pytest.mark.parametrize("recompute", [True, False])
-@pytest.mark.parametrize("N,K,D,seed", [(9, 12, 2, 21), (40, 50, 2, 22), (30, 25, 3, 23), (280, 6, 2, 24), (270, 3, 3, 25)])
+@pytest.mark.parametrize("N,K,D,seed", [(9, 12, 2, 21), (40, 50, 2, 22), (30, 25, 3, 23), (280, 6, 2, 24), (270, 3, 3, 25),
+                                        (700, 10, 2, 26)])  # (the last one: three-launch compaction, incl. its overflow path)
 def test_collision_violations_pass(ctx, N, K, D, seed, recompute):
     """Both forms of the pass: recomputing eta / l from the linearisation point (scp_collision_violations_at, the
     default: nothing streamed from HBM) and reading the stored rows (scp_collision_violations)."""

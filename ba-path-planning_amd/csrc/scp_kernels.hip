@@ -432,7 +432,10 @@ struct PairUnroll {
 };
 constexpr int PAIR_ROWS = PAIR_THREADS * PAIR_STEPS * 2;   // rows (= pairs at one k) per workgroup
 
-enum PairMode { MODE_LINEARIZE = 0, MODE_CHECK = 1, MODE_VIOLATIONS = 2, MODE_VIOL_RECOMPUTE = 3 };
+enum PairMode { MODE_LINEARIZE = 0, MODE_CHECK = 1, MODE_VIOLATIONS = 2, MODE_VIOL_RECOMPUTE = 3, MODE_SELECT = 4 };
+// MODE_SELECT: the linearisation pass WITHOUT its row stream (scp_select_pairs): the same distances, the same selection test
+// and the same a8 reductions as MODE_LINEARIZE, but eta / l are not written -- the consumer (scp_qp_add_rows_at) recomputes
+// them for the few selected rows (0.05 % at 1024 x 50) from the linearisation point.
 // MODE_VIOL_RECOMPUTE: the violations pass without the 8 (D + 1) bytes-per-row read-back: eta and R - dist are
 // recomputed from the slice of the linearisation point (P_tm) exactly as the linearise pass computed them, and
 //   l_r - (A x)_r = (R - dist) + eta.(Q_prev_i - Q_prev_j) - eta.(Q_new_i - Q_new_j) = (R - dist) - eta.(dP_i - dP_j),
@@ -455,6 +458,10 @@ struct PairArgs {
   int ablate;            // developer switch (profiling build, env SCP_PAIR_ABLATE): 1 = skip the streaming stores, 2 = force no-LDS
 };
 
+// c_i[k] = p0 + (k h) v0: the free motion a row's lower bound is measured from (scp.py:543-549).  ONE definition for the
+// prep kernel of the passes and for the row-recomputing add kernel, so that both produce the same bits.
+__device__ inline double free_motion(double p0, double v0, int k, double h) { return p0 + ((double)k * h) * v0; }
+
 // [N][K][D] -> time-major P and Q = P - (p0 + (k h) v0) (either output may be NULL); also clears the bitmap the pass
 // is about to mark (linearize), so that no memset launch is needed
 __global__ __launch_bounds__(256) void pair_prep_kernel(int N, int K, int D, double h, const double* __restrict__ pos,
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(int N, int K, int D, dou
   const int i = c / D, d = c % D;
   const double p = pos[((int64_t)i * K + k) * D + d];
   if (P_tm) P_tm[t] = p;
-  if (Q_tm) Q_tm[t] = p - (p0[c] + ((double)k * h) * v0[c]);
+  if (Q_tm) Q_tm[t] = p - free_motion(p0[c], v0[c], k, h);
 }
 
 // lexicographic pairs (i, j), i < j: row i + 1 of the triangle starts at j = i + 2.
@@ -524,6 +531,45 @@ __device__ inline Pt<D> load_pt(const double* base, int idx) {
   return r;
 }
 
+// Geometry of one pair at one time step and the compact row derived from it -- the arithmetic of scp.py:498-509, :543-549.
+// Shared by the pairwise passes and by add_rows_at_kernel (the row-free loop recomputes the selected rows with it): one
+// definition, the same bits.
+template <int D>
+struct PairGeom {
+  double diff[D], ss, inv, raw;
+  bool deg;
+};
+template <int D>
+__device__ inline PairGeom<D> pair_geom(const Pt<D>& Pi, const Pt<D>& Pj) {
+  PairGeom<D> g;
+  g.ss = 0.0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    g.diff[d] = Pi.v[d] - Pj.v[d];
+    g.ss = fma(g.diff[d], g.diff[d], g.ss);
+  }
+  g.deg = g.ss < 1e-12;  // dist < 1e-6 (scp.py:503)
+  g.inv = rsqrt_nr(fmax(g.ss, 1e-200));
+  double raw = g.ss * g.inv;
+  g.raw = fma(fma(-raw, raw, g.ss), 0.5 * g.inv, raw);  // one correction step: sqrt to < 1 ulp (0 stays 0)
+  return g;
+}
+// eta (scp.py:509; the fixed direction e_0 and dist := 1 for a degenerate pair, scp.py:503-507), the distance the row uses,
+// and  l = R + (eta.diff - dist) - eta.(c_i - c_j) = R - dist + eta.(Q_i - Q_j)  (scp.py:543-549)
+template <int D>
+__device__ inline void pair_row(const PairGeom<D>& g, const Pt<D>& Qi, const Pt<D>& Qj, double R, double (&eta)[D], double& l,
+                                double& dist) {
+  dist = g.deg ? 1.0 : g.raw;
+  double qd = 0.0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const double e_d = g.deg ? (d == 0 ? 1.0 : 0.0) : g.diff[d] * g.inv;
+    eta[d] = e_d;
+    qd = fma(e_d, Qi.v[d] - Qj.v[d], qd);
+  }
+  l = (R - dist) + qd;
+}
+
 // One workgroup = PAIR_ROWS consecutive local rows of one time step k.  The k-slices of P and Q are staged in
 // LDS once per workgroup (16-byte loads): every row then costs four LDS reads (P_i, Q_i broadcast within the
 // wave; P_j, Q_j: consecutive lanes -> consecutive 8*D-byte slots, conflict free), and the only HBM traffic is
@@ -541,7 +587,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
   const int64_t par = slice0 & 1;               // keep every thread's first row at an even local row id
   const int64_t c0 = (int64_t)blockIdx.x * PAIR_ROWS - par;  // first local pair offset of this workgroup
   constexpr bool NEED_P = MODE != MODE_VIOLATIONS;
-  constexpr bool NEED_Q = MODE != MODE_CHECK;
+  constexpr bool NEED_Q = MODE != MODE_CHECK && MODE != MODE_SELECT;
   constexpr bool VIOL = MODE == MODE_VIOLATIONS || MODE == MODE_VIOL_RECOMPUTE;  // selects violated rows, reduces max violation
 
   const double* P = NEED_P ? a.P_tm + (int64_t)k * N * D : nullptr;
@@ -665,37 +711,26 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
         sel[u][e] = false;
         if (MODE != MODE_VIOLATIONS) {
           const Pt<D> Pi = load_pt<D>(P, i), Pj = load_pt<D>(P, j);
-          double diff[D], ss = 0.0;
-#pragma unroll
-          for (int d = 0; d < D; ++d) {
-            diff[d] = Pi.v[d] - Pj.v[d];
-            ss = fma(diff[d], diff[d], ss);
-          }
-          const bool deg = ss < 1e-12;  // dist < 1e-6 (scp.py:503)
-          const double inv = rsqrt_nr(fmax(ss, 1e-200));
-          double raw = ss * inv;
-          raw = fma(fma(-raw, raw, ss), 0.5 * inv, raw);  // one correction step: sqrt to < 1 ulp (0 stays 0)
+          const PairGeom<D> g = pair_geom<D>(Pi, Pj);
+          const double* diff = g.diff;
+          const bool deg = g.deg;
+          const double inv = g.inv, raw = g.raw;
           if (MODE != MODE_VIOL_RECOMPUTE && valid[u][e]) {
             my_min = fmin(my_min, raw);
             if (raw < thr) {
               const int64_t off = off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS) + e;
-              const unsigned long long g = (unsigned long long)((int64_t)k * a.pairs + a.q_begin + off);
-              my_first = g < my_first ? g : my_first;
+              const unsigned long long g_ = (unsigned long long)((int64_t)k * a.pairs + a.q_begin + off);
+              my_first = g_ < my_first ? g_ : my_first;
             }
           }
           if (MODE == MODE_LINEARIZE) {
             const Pt<D> Qi = load_pt<D>(Q, i), Qj = load_pt<D>(Q, j);
-            const double dist = deg ? 1.0 : raw;  // scp.py:503-507 with the fixed direction e_0
-            double qd = 0.0;
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-              const double e_d = deg ? (d == 0 ? 1.0 : 0.0) : diff[d] * inv;  // scp.py:509
-              eta_v[u][e][d] = e_d;
-              qd = fma(e_d, Qi.v[d] - Qj.v[d], qd);
-            }
-            // l = R + (eta.diff - dist) - eta.(c_i - c_j) = R - dist + eta.(Q_i - Q_j)  (scp.py:543-549), where the
-            // reference's eta.diff term is kept for the degenerate rule (there eta.diff != dist)
-            l_v[u][e] = (a.R - dist) + qd;
+            double dist;
+            pair_row<D>(g, Qi, Qj, a.R, eta_v[u][e], l_v[u][e], dist);
+            sel[u][e] = valid[u][e] && ((dist - a.R) < a.margin);
+          }
+          if (MODE == MODE_SELECT) {  // the selection test of MODE_LINEARIZE on the same distance, nothing stored
+            const double dist = deg ? 1.0 : raw;
             sel[u][e] = valid[u][e] && ((dist - a.R) < a.margin);
           }
           if (MODE == MODE_VIOL_RECOMPUTE) {

@@ -855,6 +855,8 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
   }
   qp->check_seq = 0;
   qp->persist_off = false;
+  qp->persist_skip_solve = false;
+  qp->persist_gave_up_total = 0;
   qp->persist_fault = 0;
   qp->persist_cap_nW = -1;
   qp->persist_cap = 0;
@@ -936,6 +938,7 @@ extern "C" int scp_qp_set_problem(scp_qp* qp, const double* limits, const double
                                         qp->d.uf));
   qp->problem_set = true;
   qp->reset_done = false;
+  qp->persist_off = false;  // a give-up is a property of the moment (another kernel held the CUs), not of the object
   return SCP_OK;
 }
 
@@ -961,6 +964,7 @@ extern "C" int scp_qp_reset(scp_qp* qp, const double* x0) {
   }
   qp->nW = 0;
   qp->persist_cap_nW = -1;
+  qp->persist_off = false;  // every new QP tries the persistent path again
   qp->rho = qp->st.rho;
   qp->cg1_ready = false;
   qp->csr_valid = false;
@@ -1025,8 +1029,10 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
   memset(info, 0, sizeof(*info));
   info->status_val = -2;  // OSQP_MAX_ITER_REACHED
   qp->cg1_ready = false;  // settings may have changed between calls
+  qp->persist_skip_solve = false;
   SCP_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   int cg_total = 0, it = 0;
+  int pipes = 0;
   double rp = INFINITY, rd = INFINITY;
   while (it < st.max_iter) {
     // fixed rows only (everything is column-local): every iteration up to the next termination check goes into ONE
@@ -1039,15 +1045,20 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
     const bool cg1_big = bigk && st.cg_iters == 1 && qp->nW > 0;
     const bool cg1_it = fused && st.cg_iters == 1 && qp->nW > 0;  // its update kernel emits delta-y itself
     bool persist_done = false;
-    if (cg1_it && scp_qp_persist_eligible(qp)) {
+    if (cg1_it && !qp->persist_skip_solve && scp_qp_persist_eligible(qp)) {
       int ran = 0, code = 0, it_done = it;
       QP_CHECK(scp_qp_cg1_persist(qp, it, &ran, &code, &it_done));
       if (ran && code == SCP_PERSIST_GAVE_UP) {
-        // its workgroups were not all resident at once (e.g. the device is shared with another stream's kernels): nothing
-        // was written back, so the solve goes on from the same state on the three-launch pipeline and stays there
+        // its workgroups were not all resident at once (e.g. the device is shared with another process's kernels): nothing
+        // was written back, so the solve goes on from the same state on the three-launch pipeline and stays there until
+        // the next scp_qp_reset re-arms the persistent path
         qp->persist_off = true;
         qp->persist_epoch = 0;
+        ++info->persist_gave_up;
       } else if (ran) {
+        ++info->persist_launches;
+        info->rho_switches_in_kernel += qp->persist_rho_switches;
+        pipes |= 1 << SCP_PIPE_PERSIST;
         cg_total += it_done - it;
         it = it_done;
         qp->qx_fresh = true;  // the kernel's last check left F x and S0 x exact
@@ -1077,11 +1088,11 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
           SCP_HIP_CHECK(ctx, hipMemcpyAsync(qp->d.dyc, qp->d.yc, (size_t)qp->nW * sizeof(double),
                                             hipMemcpyDeviceToDevice, ctx->stream));
       }
-      if (cg1_it) QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total, with_dy));
-      else if (cg1_big) QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total, false));
-      else if (qp0_it) QP_CHECK(scp_qp_qp0_iterations(qp, n_it, with_dy ? qp->d.dyf : nullptr));
-      else if (fused) QP_CHECK(scp_qp_fused_iteration(qp, &cg_total));
-      else QP_CHECK(admm_iteration(qp, &cg_total));
+      if (cg1_it) { QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total, with_dy)); pipes |= 1 << SCP_PIPE_CG1; }
+      else if (cg1_big) { QP_CHECK(scp_qp_cg1_iteration(qp, &cg_total, false)); pipes |= 1 << SCP_PIPE_CG1_BIGK; }
+      else if (qp0_it) { QP_CHECK(scp_qp_qp0_iterations(qp, n_it, with_dy ? qp->d.dyf : nullptr)); pipes |= 1 << SCP_PIPE_QP0; }
+      else if (fused) { QP_CHECK(scp_qp_fused_iteration(qp, &cg_total)); pipes |= 1 << SCP_PIPE_FUSED; }
+      else { QP_CHECK(admm_iteration(qp, &cg_total)); pipes |= 1 << SCP_PIPE_GENERIC; }
     }
     if (will_check) {
       if (persist_done) {
@@ -1145,6 +1156,7 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
   info->r_dual = rd;
   info->rho = qp->rho;
   info->solve_ms = ms;
+  info->pipeline = pipes;
   return SCP_OK;
 }
 
@@ -1252,5 +1264,6 @@ extern "C" int scp_qp_debug_set(scp_qp* qp, const char* key, int value) {
     if (value >= 0) qp->persist_off = value != 0;
     return qp->persist_off ? 1 : 0;
   }
+  if (!strcmp(key, "persist_gave_up_total")) return qp->persist_gave_up_total;  // (read only)
   return scp_fail(qp->ctx, SCP_ERR_INVALID, "qp_debug_set: unknown key %s", key);
 }

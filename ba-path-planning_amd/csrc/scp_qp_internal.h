@@ -87,7 +87,11 @@ struct scp_qp {
   unsigned long long check_seq;  // value the flag takes when the current check has finished
   // persistent single-step kernel (scp_qp_persist.hip)
   int persist_fault;                 // test hook: the next n persistent launches wait for a workgroup that does not exist
-  bool persist_off;                  // a launch gave up (workgroups not co-resident): stay on the three-launch pipeline
+  bool persist_off;                  // a launch gave up (workgroups not co-resident): three-launch pipeline until the next
+                                     // scp_qp_reset / scp_qp_set_problem re-arms the persistent path
+  bool persist_skip_solve;           // the CUs for a persistent launch were not free: this scp_qp_solve call stays on the
+                                     // three-launch pipeline (cleared at the start of every call)
+  int persist_gave_up_total;         // give-ups over the life of the object (scp_qp_debug_set "persist_gave_up_total")
   int64_t persist_cap_nW;            // working-set size that overflowed the LDS entry tables (-1: none): not tried again
   int persist_cap;                   // LDS entry capacity per workgroup (all the LDS that is left)
   unsigned long long persist_epoch;  // ADMM steps run by persistent launches so far: the step tags of the granules never repeat
@@ -119,9 +123,18 @@ int scp_qp_csr_build(scp_qp* qp);
 int scp_qp_rows_gather(scp_qp* qp, bool init, const double* Q);
 int scp_qp_cg1_prepare(scp_qp* qp);
 constexpr int SCP_SYNC_WORDS = 16;  // u64: give-up word | scratch
-constexpr int SCP_GPART_WORDS = 2 * 256 * 4;  // two buffers x (at most one workgroup per CU) x two doubles as granule pairs
-constexpr int SCP_GCHECK_WORDS = 256 * 9 * 2;  // nine check results per workgroup as granule pairs
+// Workgroups of a persistent launch: at most one per CU (all resident), and the exchange buffers below are sized for
+// exactly this many (+1: the fault-injection hook announces one workgroup more than it launches).
+constexpr int SCP_PERSIST_MAX_WG = 256;
+constexpr int SCP_GPART_WORDS = 2 * (SCP_PERSIST_MAX_WG + 1) * 4;  // two buffers x workgroups x two doubles as granule pairs
+constexpr int SCP_GCHECK_WORDS = (SCP_PERSIST_MAX_WG + 1) * 9 * 2;  // nine check results per workgroup as granule pairs
 bool scp_qp_persist_eligible(const scp_qp* qp);
+// Compute units claimed by the persistent launches in flight on one device of THIS process (solver threads on several
+// streams, compute-trajectories-batch): a launch needs all its workgroups resident at once, so it first claims one CU per
+// workgroup.  scp_persist_claim waits up to `wait_ms` for the claim to fit (returns false otherwise: the caller runs this
+// batch of iterations on the three-launch pipeline instead of discovering the shortage through a spin timeout).
+bool scp_persist_claim(int device, int n_cu_total, int n_wg, int wait_ms);
+void scp_persist_release(int device, int n_wg);
 constexpr int SCP_PERSIST_GAVE_UP = 2;  // exit code of the persistent kernel: a spin timed out, nothing was written back
 int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done);
 // (re)pack F, Ft, S0, S0t, HS, Minv into the MFMA operand order; called at the end of build_kkt

@@ -25,6 +25,9 @@
 // state back, and the host repeats the iterations on the three-launch pipeline.
 #include "scp_qp_device.h"
 
+#include <cerrno>
+#include <chrono>
+
 
 namespace {
 using namespace scpdev;
@@ -696,6 +699,12 @@ __global__ __launch_bounds__(64 * persist_apb(D)) void cg1_persist_kernel(Persis
   }
   }  // batches
 
+  // The exit decision is collective: a workgroup that timed out has raised the give-up word BEFORE the cell or partial it
+  // was waiting for appeared, so every workgroup that got past that exchange afterwards sees the word here and leaves
+  // without writing back as well (the host additionally drops its carried-state flags on a give-up).
+  if (ok && __syncthreads_or(threadIdx.x == 0 &&
+                             __hip_atomic_load(A.give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u))
+    ok = false;
   if (!ok) {
     if (threadIdx.x == 0) {
       __hip_atomic_store(A.host_status, (unsigned)EXIT_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -769,7 +778,8 @@ bool scp_qp_persist_eligible(const scp_qp* qp) {
   if (qp->K > 64 || qp->nW <= 0 || qp->persist_off) return false;
   const int apb = persist_apb(qp->D);
   const int nblk = (qp->N + apb - 1) / apb;
-  return nblk <= qp->ctx->n_cu;  // one workgroup per CU, all resident (grid-wide rendezvous)
+  // one workgroup per CU, all resident (grid-wide rendezvous); gpart / gcheck hold SCP_PERSIST_MAX_WG (+1) workgroups
+  return nblk <= qp->ctx->n_cu && nblk <= SCP_PERSIST_MAX_WG;
 }
 
 // Run ADMM iterations from iteration count `it0` of the current solve in ONE launch, termination checks included, until
@@ -808,10 +818,22 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   // never complete -- the bounded spins must time out, every workgroup must leave without writing state back, and the
   // host must carry on with the three-launch pipeline
   const int nblk_expected = nblk + (qp->persist_fault > 0 ? 1 : 0);
-  if (qp->persist_fault > 0) --qp->persist_fault;
   const size_t lds = persist_lds_bytes(K, D, qp->persist_cap, nblk_expected);
   if (lds > 160 * 1024) return SCP_OK;  // too many rows around one block of agents: three-launch pipeline
   const int budget = st.max_iter - it0;  // at most this many steps in this launch
+  if (budget <= 0) return SCP_OK;  // nothing to run (the kernel's check would read tags and delta-y of an earlier launch)
+  // Residency: every workgroup must be on the chip at once.  Claim one CU per workgroup among the persistent launches of
+  // this device (all processes of this user, scp_persist_claim); a claim that does not fit within 200 ms sends this solve
+  // to the three-launch pipeline instead of letting 2^20 polls find out.
+  if (!scp_persist_claim(ctx->device, ctx->n_cu, nblk, 200)) {
+    qp->persist_skip_solve = true;
+    return SCP_OK;
+  }
+  if (qp->persist_fault > 0) --qp->persist_fault;
+  struct ClaimGuard {
+    int device, n;
+    ~ClaimGuard() { scp_persist_release(device, n); }
+  } claim_guard{ctx->device, nblk};
   PersistArgs a;
   a.K = K; a.N = qp->N; a.nblk = nblk_expected; a.ent_cap = qp->persist_cap;
   a.it0 = it0; a.max_iter = st.max_iter; a.check_every = st.check_termination;
@@ -883,6 +905,13 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
     *ran = 0;
     return SCP_OK;
   }
+  if (*code == SCP_PERSIST_GAVE_UP) {
+    // Nothing should have been written back; if a workgroup got through after another had timed out (the kernel's exit
+    // decision closes that window but cannot exclude it), the carried slabs no longer match x / z / y: rebuild them.
+    qp->cg1_ready = false;
+    qp->qx_fresh = false;
+    ++qp->persist_gave_up_total;
+  }
   if (*code != SCP_PERSIST_GAVE_UP) {
     qp->persist_epoch += (u64)(*it_done - it0);  // one tag per ADMM step
     // rho switches the kernel made by itself (scp_qp_solve adopts the value and points d.* at that slot)
@@ -890,6 +919,121 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
     qp->persist_rho = ((volatile double*)qp->h_scal)[SL_COUNT + SCP_RESID_CAP + 3];
   }
   return SCP_OK;
+}
+
+// ---- residency bookkeeping of the persistent launches ---------------------------------------------------------------------
+// One table per (user, GPU) in POSIX shared memory, so that solver threads of SEVERAL processes on one GPU (compute-
+// trajectories-batch: processes x streams) account for each other: `total` = CUs claimed by launches in flight; every
+// process owns a slot {pid, claimed} so that the claims of a process that died can be taken back (kill(pid, 0) == ESRCH).
+// Without shared memory (no /dev/shm) the table is process-local.
+#include <fcntl.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <mutex>
+
+namespace {
+constexpr int RES_SLOTS = 128, RES_DEVICES = 16;
+struct ResTable {
+  std::atomic<int> total;
+  struct Slot {
+    std::atomic<int> pid, claimed;
+  } slot[RES_SLOTS];
+};
+ResTable g_res_local[RES_DEVICES];
+ResTable* g_res[RES_DEVICES];
+int g_res_slot[RES_DEVICES];
+std::mutex g_res_mu;
+
+ResTable* res_table(int device, int* my_slot) {
+  const int dv = device >= 0 && device < RES_DEVICES ? device : 0;
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  if (!g_res[dv]) {
+    ResTable* t = nullptr;
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) snprintf(bus, sizeof(bus), "dev%d", device);
+    for (char* c = bus; *c; ++c)
+      if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+    char name[128];
+    snprintf(name, sizeof(name), "/scp_hip_persist_%u_%s", (unsigned)getuid(), bus);
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd >= 0) {
+      if (ftruncate(fd, sizeof(ResTable)) == 0) {
+        void* m = mmap(nullptr, sizeof(ResTable), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m != MAP_FAILED) t = static_cast<ResTable*>(m);  // (a fresh segment is zero-filled: empty table)
+      }
+      close(fd);
+    }
+    if (!t) t = &g_res_local[dv];
+    // this process's slot: a free one, or one whose owner is gone
+    const int me = (int)getpid();
+    int mine = -1;
+    for (int i = 0; i < RES_SLOTS && mine < 0; ++i) {
+      int owner = t->slot[i].pid.load();
+      if (owner == me) {  // a slot left by an earlier process with this pid: its claims are stale
+        const int lost = t->slot[i].claimed.exchange(0);
+        if (lost > 0) t->total.fetch_sub(lost);
+        mine = i;
+        break;
+      }
+      if (owner != 0 && !(kill(owner, 0) != 0 && errno == ESRCH)) continue;
+      if (owner != 0) {  // dead owner: its claims go back first
+        const int lost = t->slot[i].claimed.exchange(0);
+        if (lost > 0) t->total.fetch_sub(lost);
+      }
+      if (t->slot[i].pid.compare_exchange_strong(owner, me)) mine = i;
+    }
+    g_res[dv] = t;
+    g_res_slot[dv] = mine;  // (-1: table full -- claims still count in `total`, only the crash recovery is lost)
+  }
+  *my_slot = g_res_slot[dv];
+  return g_res[dv];
+}
+
+// give back the claims of processes that no longer exist
+void res_reap(ResTable* t) {
+  for (int i = 0; i < RES_SLOTS; ++i) {
+    int owner = t->slot[i].pid.load();
+    if (owner == 0 || owner == (int)getpid()) continue;
+    if (kill(owner, 0) != 0 && errno == ESRCH && t->slot[i].pid.compare_exchange_strong(owner, 0)) {
+      const int lost = t->slot[i].claimed.exchange(0);
+      if (lost > 0) t->total.fetch_sub(lost);
+    }
+  }
+}
+}  // namespace
+
+bool scp_persist_claim(int device, int n_cu_total, int n_wg, int wait_ms) {
+  int slot = -1;
+  ResTable* t = res_table(device, &slot);
+  const auto t0 = std::chrono::steady_clock::now();
+  bool reaped = false;
+  for (;;) {
+    const int before = t->total.fetch_add(n_wg);
+    if (before + n_wg <= n_cu_total) {
+      if (slot >= 0) t->slot[slot].claimed.fetch_add(n_wg);
+      return true;
+    }
+    t->total.fetch_sub(n_wg);
+    if (!reaped) {  // claims of a crashed process would block everybody for ever
+      res_reap(t);
+      reaped = true;
+      continue;
+    }
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(wait_ms)) return false;
+    struct timespec ts = {0, 20000};
+    nanosleep(&ts, nullptr);
+  }
+}
+
+void scp_persist_release(int device, int n_wg) {
+  int slot = -1;
+  ResTable* t = res_table(device, &slot);
+  if (slot >= 0) t->slot[slot].claimed.fetch_sub(n_wg);
+  t->total.fetch_sub(n_wg);
 }
 
 #ifdef SCP_PHASE_PROFILE

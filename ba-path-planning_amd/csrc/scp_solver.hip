@@ -127,7 +127,16 @@ int solve_joint_qp(scp_solver* s, const double* acc_in, const double* limits, co
   const int N = s->N, K = s->K, D = s->D;
   const size_t nbytes = (size_t)N * K * D * sizeof(double);
   int max_iter = o->max_iter;
-  const scp_qp_settings saved = s->st;
+  // the per-QP tolerances (polish) and the per-round iteration budget go into s->st: put the caller's settings back on EVERY
+  // exit path, or an error return would leave a pooled solver object with polish tolerances for all later scenarios
+  struct RestoreSettings {
+    scp_solver* s;
+    scp_qp_settings saved;
+    ~RestoreSettings() {
+      s->st = saved;
+      if (s->qp) (void)scp_qp_update_settings(s->qp, &saved);
+    }
+  } restore{s, s->st};
   if (eps > 0.0) {
     s->st.eps_abs = s->st.eps_rel = eps;
     max_iter = std::max(max_iter, 40000);
@@ -166,6 +175,10 @@ int solve_joint_qp(scp_solver* s, const double* acc_in, const double* limits, co
     rec->cg_iters_total += info.cg_iters_total;
     rec->rho_updates += info.rho_updates;
     rec->solve_ms += info.solve_ms;
+    rec->pipeline |= info.pipeline;
+    rec->persist_launches += info.persist_launches;
+    rec->persist_gave_up += info.persist_gave_up;
+    rec->rho_switches_in_kernel += info.rho_switches_in_kernel;
     SV_CHECK(scp_qp_get_solution(s->qp, s->x));
     SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, s->x, p0, v0, s->pos_b, nullptr));
     for (;;) {
@@ -194,7 +207,6 @@ int solve_joint_qp(scp_solver* s, const double* acc_in, const double* limits, co
   rec->max_violation = max_v;
   rec->linearize_ms = lin_ms;
   rec->violations_ms = viol_ms;
-  s->st = saved;
   return SCP_OK;
 }
 
@@ -302,6 +314,7 @@ extern "C" int scp_solver_solve(scp_solver* s, const double* limits, const doubl
   r0->status_val = i0.status_val; r0->iter = i0.iter; r0->rho_updates = i0.rho_updates; r0->cg_iters_total = i0.cg_iters_total;
   r0->working_rows = i0.working_rows; r0->r_prim = i0.r_prim; r0->r_dual = i0.r_dual; r0->rho = i0.rho; r0->solve_ms = i0.solve_ms;
   r0->rounds = 1;
+  r0->pipeline = i0.pipeline;
   res->n_records = 1;
   if (i0.status_val != 1 && i0.status_val != 2) {  // scp.py:363-365: the caller raises "OSQP failed: <status>"
     res->qp0_status = i0.status_val;

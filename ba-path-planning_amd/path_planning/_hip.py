@@ -21,6 +21,15 @@ UINT64_MAX = (1 << 64) - 1
 STATUS_TEXT = {1: "solved", 2: "solved inaccurate", -2: "maximum iterations reached", -3: "primal infeasible"}
 
 
+# enum scp_qp_pipeline: bit numbers of scp_qp_info.pipeline
+PIPELINES = ("qp0", "persistent", "persistent16", "three-launch", "three-launch-bigK", "fused", "generic")
+
+
+def pipeline_names(mask):
+    """'persistent+three-launch' ... for the bit mask scp_qp_solve reports (which pipelines ran its ADMM iterations)"""
+    return "+".join(n for b, n in enumerate(PIPELINES) if mask >> b & 1) or "none"
+
+
 class HipError(RuntimeError):
     def __init__(self, code, text):
         super().__init__(f"libscp_hip error {code}: {text}")
@@ -57,15 +66,19 @@ class QpRecord(C.Structure):
 
     _fields_ = [
         ("status_val", C.c_int32), ("iter", C.c_int32), ("rho_updates", C.c_int32), ("cg_iters_total", C.c_int32),
-        ("rounds", C.c_int32), ("reserved", C.c_int32), ("working_rows", C.c_int64), ("unresolved_rows", C.c_int64),
+        ("rounds", C.c_int32), ("pipeline", C.c_int32), ("working_rows", C.c_int64), ("unresolved_rows", C.c_int64),
         ("added", C.c_int64 * MAX_ROUNDS_RECORDED), ("r_prim", C.c_double), ("r_dual", C.c_double), ("rho", C.c_double),
         ("solve_ms", C.c_double), ("max_violation", C.c_double), ("rel_step", C.c_double), ("time_sec", C.c_double),
         ("linearize_ms", C.c_double), ("violations_ms", C.c_double),
+        ("persist_launches", C.c_int32), ("persist_gave_up", C.c_int32), ("rho_switches_in_kernel", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k in ("status_val", "iter", "rho_updates", "cg_iters_total", "working_rows", "r_prim",
-                                            "r_dual", "rho", "solve_ms")}
+                                            "r_dual", "rho", "solve_ms", "persist_launches", "persist_gave_up",
+                                            "rho_switches_in_kernel")}
+        d["pipeline"] = pipeline_names(self.pipeline)
         d["status"] = STATUS_TEXT.get(self.status_val, str(self.status_val))
         d["rounds"] = int(self.rounds)
         d["added"] = [int(self.added[i]) for i in range(min(self.rounds, MAX_ROUNDS_RECORDED))]
@@ -92,16 +105,18 @@ class QpInfo(C.Structure):
     _fields_ = [
         ("status_val", C.c_int32), ("iter", C.c_int32), ("rho_updates", C.c_int32), ("cg_iters_total", C.c_int32),
         ("working_rows", C.c_int64), ("r_prim", C.c_double), ("r_dual", C.c_double), ("rho", C.c_double),
-        ("solve_ms", C.c_double),
+        ("solve_ms", C.c_double), ("pipeline", C.c_int32), ("persist_launches", C.c_int32),
+        ("persist_gave_up", C.c_int32), ("rho_switches_in_kernel", C.c_int32),
     ]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["pipeline"] = pipeline_names(self.pipeline)
         d["status"] = STATUS_TEXT.get(self.status_val, str(self.status_val))
         return d
 
 
-ABI_VERSION = 3  # SCP_ABI_VERSION of include/scp_hip.h this binding matches (checked when the library is loaded)
+ABI_VERSION = 4  # SCP_ABI_VERSION of include/scp_hip.h this binding matches (checked when the library is loaded)
 
 EXPORTS = [
     "scp_set_host_wait", "scp_abi_version", "scp_ctx_create", "scp_ctx_destroy", "scp_last_error", "scp_ctx_synchronize",

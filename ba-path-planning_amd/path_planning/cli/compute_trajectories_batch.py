@@ -118,6 +118,11 @@ def run_single_trial(N, cfg, rng=None, seed=None, device=None, scenario=None, sa
             qp_status=[q["status"] for q in qps],
             qp_residuals=[[float(q["r_prim"]), float(q["r_dual"])] for q in qps],
             working_rows=[int(q["working_rows"]) for q in qps],
+            # which ADMM pipeline ran each QP, and whether a persistent launch had to give up (CUs taken by another
+            # process): a fallen-back solve is slower and differs in the last bits -- visible here, not only in the time
+            qp_pipeline=[q.get("pipeline", "none") for q in qps],
+            persist_gave_up=int(sum(int(q.get("persist_gave_up", 0)) for q in qps)),
+            rho_switches_in_kernel=int(sum(int(q.get("rho_switches_in_kernel", 0)) for q in qps)),
         )
         if cfg.get("validate", False):
             record["min_pair_distance"] = float(solver.validate_solution()["min_pair_distance"])

@@ -465,7 +465,26 @@ class SCP:
         pp = self._ensure_pairs()
         qp = self._ensure_qp()
         max_iter = int(self._qp_overrides.get("max_iter", 10000))  # scp.py:442
-        eps_saved = (qp.settings.eps_abs, qp.settings.eps_rel)
+        saved = (qp.settings.eps_abs, qp.settings.eps_rel, qp.settings.max_iter)
+        try:
+            x, info, total, added, max_v = self._joint_qp_rounds(acc, p0, v0, pp, qp, max_iter, eps)
+        finally:
+            # the per-QP tolerances (polish) and the per-round iteration budget must not outlive this call, whatever
+            # happens inside it (self._qp: the solver may have moved to a larger workspace meanwhile)
+            self._qp.update_settings(eps_abs=saved[0], eps_rel=saved[1], max_iter=saved[2])
+        self._last_qp_info = dict(info, **total, rounds=len(added), added=added, unresolved_rows=added[-1],
+                                  max_violation=max_v)
+        if info["status_val"] not in (1, 2):  # scp.py:446-447
+            self._print(f"Warning: OSQP status {info['status']}")
+        elif added[-1]:
+            # constraint generation stopped (max_rounds or the iteration budget) with violated rows still outside the
+            # working set: x solves the QP over the working set only, not the full joint QP of scp.py:399-451
+            self._print(f"Warning: OSQP status constraint generation stopped with {added[-1]} violated collision rows "
+                        f"outside the working set (max violation {max_v:.3e})")
+        return x
+
+    def _joint_qp_rounds(self, acc, p0, v0, pp, qp, max_iter, eps):
+        """The rounds of _solve_with_avoidance_constraints: linearise, working set, ADMM, violations pass, repeat."""
         if eps is not None:
             qp.update_settings(eps_abs=float(eps), eps_rel=float(eps))
             max_iter = max(max_iter, 40000)  # three more digits take a few times OSQP's budget
@@ -490,7 +509,9 @@ class SCP:
         info = None
         x = acc
         max_v = 0.0
-        total = {"iter": 0, "cg_iters_total": 0, "rho_updates": 0, "solve_ms": 0.0}
+        total = {"iter": 0, "cg_iters_total": 0, "rho_updates": 0, "solve_ms": 0.0, "persist_launches": 0,
+                 "persist_gave_up": 0, "rho_switches_in_kernel": 0}
+        pipes = set()
         for rnd in range(self.max_rounds):
             qp.update_settings(max_iter=max(max_iter - used, 1))
             info = qp.solve()
@@ -500,6 +521,7 @@ class SCP:
             used += info["iter"]
             for k in total:
                 total[k] += info[k]
+            pipes.update(info["pipeline"].split("+"))
             x = qp.solution()
             self.shard.broadcast(x)
             pos_new, _ = self._kinematics(x, want_vel=False)
@@ -517,19 +539,8 @@ class SCP:
                 # continue in a larger workspace: the state of the solve travels along
                 qp = self._grow_qp(qp.n_rows + int(new_rows.numel()), keep_state=True)
                 qp.add_rows(new_rows, n_eta, n_l)
-
-        if eps is not None:
-            self._qp.update_settings(eps_abs=eps_saved[0], eps_rel=eps_saved[1])
-        self._last_qp_info = dict(info, **total, rounds=len(added), added=added, unresolved_rows=added[-1],
-                                  max_violation=max_v)
-        if info["status_val"] not in (1, 2):  # scp.py:446-447
-            self._print(f"Warning: OSQP status {info['status']}")
-        elif added[-1]:
-            # constraint generation stopped (max_rounds or the iteration budget) with violated rows still outside the
-            # working set: x solves the QP over the working set only, not the full joint QP of scp.py:399-451
-            self._print(f"Warning: OSQP status constraint generation stopped with {added[-1]} violated collision rows "
-                        f"outside the working set (max violation {max_v:.3e})")
-        return x
+        total["pipeline"] = "+".join(n for n in _hip.PIPELINES if n in pipes) or "none"
+        return x, info, total, added, max_v
 
     # ------------------------------------------------------------------------------------------------
     # a8: avoidance check (scp.py:597-615)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SCP_ABI_VERSION 3
+#define SCP_ABI_VERSION 4
 
 typedef enum scp_status {
   SCP_OK = 0,
@@ -91,7 +91,23 @@ typedef struct scp_qp_info {
   double r_prim, r_dual;
   double rho;
   double solve_ms;      /* device time of this call (HIP events on the ctx stream) */
+  int32_t pipeline;     /* which pipelines ran the ADMM iterations of this call: OR of (1 << scp_qp_pipeline) */
+  int32_t persist_launches;       /* persistent launches of this call that ran (their steps are in `iter`) */
+  int32_t persist_gave_up;        /* persistent launches that timed out on a workgroup and left without writing state
+                                     back; the iterations were repeated on the three-launch pipeline */
+  int32_t rho_switches_in_kernel; /* adaptive-rho updates made inside a persistent launch (included in rho_updates) */
 } scp_qp_info;
+
+/* the pipelines of scp_qp_solve (bit numbers of scp_qp_info.pipeline / scp_qp_record.pipeline) */
+typedef enum scp_qp_pipeline {
+  SCP_PIPE_QP0 = 0,        /* fixed rows only: all steps up to a check in one column-local launch */
+  SCP_PIPE_PERSIST = 1,    /* persistent single-step kernel, one wave per agent, 16/D agents per workgroup */
+  SCP_PIPE_PERSIST16 = 2,  /* its lean form: 16 agents per workgroup (2-D, 2048 < N <= 4096) */
+  SCP_PIPE_CG1 = 3,        /* single-step pipeline, three launches per ADMM step */
+  SCP_PIPE_CG1_BIGK = 4,   /* the same with one workgroup per column (K > 120) */
+  SCP_PIPE_FUSED = 5,      /* cg_iters > 1: fused column-block chains */
+  SCP_PIPE_GENERIC = 6     /* one product per launch */
+} scp_qp_pipeline;
 
 int scp_abi_version(void);
 /* How host threads wait for a kernel's completion word (process-wide): 0 = spin (default: lowest latency, one core per
@@ -229,7 +245,8 @@ typedef struct scp_solve_options {
 typedef struct scp_qp_record {
   int32_t status_val;       /* of the last constraint-generation round */
   int32_t iter;             /* ADMM iterations, all rounds */
-  int32_t rho_updates, cg_iters_total, rounds, reserved;
+  int32_t rho_updates, cg_iters_total, rounds;
+  int32_t pipeline;         /* OR over the rounds of scp_qp_info.pipeline */
   int64_t working_rows, unresolved_rows;
   int64_t added[SCP_MAX_ROUNDS_RECORDED]; /* rows found by the violations pass after each round */
   double r_prim, r_dual, rho, solve_ms, max_violation;
@@ -237,6 +254,7 @@ typedef struct scp_qp_record {
   double time_sec;          /* wall time of the SCP iteration */
   double linearize_ms;      /* device time of the linearisation kernel alone (HIP events around that launch) */
   double violations_ms;     /* device time of the last violations kernel */
+  int32_t persist_launches, persist_gave_up, rho_switches_in_kernel, reserved;  /* sums over the rounds (scp_qp_info) */
 } scp_qp_record;
 
 typedef struct scp_solve_result {

@@ -370,7 +370,22 @@ def test_persistent_kernel_give_up_falls_back(ctx):
         info = qp.solve()
         if mode == "fault":
             assert qp.debug_set("persist_off", -1) == 1 and qp.debug_set("persist_fault", -1) == 0
+            # the fallback is visible in the result, not only in the time (scp_qp_info)
+            assert info["persist_gave_up"] == 1 and info["persist_launches"] == 0 and info["pipeline"] == "three-launch"
+            assert qp.debug_set("persist_gave_up_total", -1) == 1
+        else:
+            assert info["persist_gave_up"] == 0 and info["pipeline"] == "three-launch"
         out[mode] = (info, qp.solution().cpu().numpy())
+        if mode == "fault":
+            # a give-up belongs to the moment, not to the object: the next QP of the same object is back on the persistent
+            # kernel (scp_qp_reset re-arms it) and says so
+            qp.reset(ctx.tensor(x0))
+            qp.add_rows(torch.as_tensor(W, dtype=torch.int64, device=ctx.tdev), ctx.tensor(eta[W]), ctx.tensor(l_col[W]))
+            assert qp.debug_set("persist_off", -1) == 0
+            again = qp.solve()
+            assert again["pipeline"] == "persistent" and again["persist_launches"] >= 1 and again["persist_gave_up"] == 0
+            assert again["status_val"] == 1 and again["rho_switches_in_kernel"] <= again["rho_updates"]
+            assert qp.debug_set("persist_gave_up_total", -1) == 1
         qp.close()
     assert out["fault"][0]["status_val"] == out["three_launch"][0]["status_val"] == 1
     assert out["fault"][0]["iter"] == out["three_launch"][0]["iter"]

@@ -84,6 +84,11 @@ int scp_ctx_wait_stats(scp_ctx* ctx, scp_pair_stats* out);
 int scp_qp_add_rows_from_pass(scp_qp* qp, int64_t n, const int64_t* rows, const double* eta, const double* l_col,
                               int64_t q_begin, int64_t q_end);
 
+// working rows [base, base + n) of a QP with eta / l recomputed from the linearisation point (scp_qp_add_rows_at)
+int scp_launch_add_rows_at(scp_ctx* ctx, int N, int K, int D, int64_t base, int64_t n, const int64_t* rows,
+                           const double* pos_prev, const double* p0, const double* v0, double R, double h, const double* Qx,
+                           int64_t* w_row, int* wk, int* wi, int* wj, double* weta, double* wl, double* zc, double* yc);
+
 // ---- internal launchers (time-major device layout [K][C], C = N*D) --------------------------------
 // Y[R][C] = alpha * A[R][M] X[M][C] + beta * Y   (row-major; A small and L2 resident)
 int scp_launch_gemm(scp_ctx* ctx, int use_mfma, int R, int M, int C, double alpha, const double* A,

@@ -891,7 +891,7 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
   int rc = ensure_tm(ctx, 2 * slice * sizeof(double));
   if (rc) return rc;
   double* P_tm = MODE != MODE_VIOLATIONS ? ctx->tm_scratch : nullptr;
-  double* Q_tm = MODE != MODE_CHECK ? ctx->tm_scratch + slice : nullptr;
+  double* Q_tm = (MODE != MODE_CHECK && MODE != MODE_SELECT) ? ctx->tm_scratch + slice : nullptr;
   if (MODE == MODE_VIOL_RECOMPUTE)
     hipLaunchKernelGGL(pair_prep_delta_kernel, dim3(scp_cdiv((int64_t)N * K * D, 256)), dim3(256), 0, ctx->stream, N, K, D,
                        pos_ref_layout, p0, P_tm, Q_tm, a.stats);
@@ -1242,6 +1242,89 @@ extern "C" int scp_linearize_pairs(scp_ctx* ctx, int N, int K, int D, double R, 
   rc = launch_pair_pass<MODE_LINEARIZE>(ctx, a, pos_prev, p0, v0, sel_bitmap, words);  // (its prep kernel clears the map)
   if (rc) return rc;
   return launch_compaction(ctx, sel_bitmap, words, nq, q_begin, a.pairs, sel_rows, sel_cap, nullptr, stats);
+}
+
+extern "C" int scp_select_pairs(scp_ctx* ctx, int N, int K, int D, double R, int64_t q_begin, int64_t q_end,
+                                const double* pos_prev, double margin, int64_t* sel_rows, int64_t sel_cap,
+                                uint32_t* sel_bitmap, scp_pair_stats* stats) {
+  if (!ctx) return SCP_ERR_INVALID;
+  int rc = check_pair_range(ctx, N, K, D, q_begin, q_end);
+  if (rc) return rc;
+  SCP_REQUIRE(ctx, pos_prev && sel_bitmap && stats && (sel_rows || sel_cap == 0), "select_pairs: null pointer");
+  const int64_t nq = q_end - q_begin;
+  PairArgs a{};
+  a.N = N; a.K = K; a.D = D; a.R = R; a.h = 0.0;
+  a.q_begin = q_begin; a.q_end = q_end; a.pairs = scp_pairs(N);
+  a.margin = margin;
+  a.bitmap = sel_bitmap; a.mark = sel_bitmap; a.stats = stats;
+  a.eta_stride = scp_eta_stride(K, nq);
+  const int64_t words = (K * nq + 31) / 32;
+  rc = ensure_cmp(ctx, words);
+  if (rc) return rc;
+  rc = launch_pair_pass<MODE_SELECT>(ctx, a, pos_prev, nullptr, nullptr, sel_bitmap, words);  // (its prep kernel clears the map)
+  if (rc) return rc;
+  return launch_compaction(ctx, sel_bitmap, words, nq, q_begin, a.pairs, sel_rows, sel_cap, nullptr, stats);
+}
+
+// Working rows appended with eta / l RECOMPUTED from the linearisation point (the row-free loop: scp_select_pairs wrote no
+// rows): decode (k, i, j), the two positions of the pair at step k from pos_prev ([N][K][D]), then pair_geom / pair_row --
+// the very functions of the linearisation kernel, on the same operands (Q = P - free_motion as its prep kernel forms it):
+// bit-identical eta and l.  z = max(A x, l), y = 0 as add_rows_kernel.
+template <int D>
+__global__ __launch_bounds__(256) void add_rows_at_kernel(int N, int K, int64_t C, int64_t pairs, int64_t base, int64_t n,
+                                                           const int64_t* __restrict__ rows,
+                                                           const double* __restrict__ pos_prev,
+                                                           const double* __restrict__ p0, const double* __restrict__ v0,
+                                                           double R, double h, const double* __restrict__ Qx,
+                                                           int64_t* __restrict__ w_row, int* __restrict__ wk,
+                                                           int* __restrict__ wi, int* __restrict__ wj,
+                                                           double* __restrict__ weta, double* __restrict__ wl,
+                                                           double* __restrict__ zc, double* __restrict__ yc) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const int64_t r = rows[t];
+  const int k = (int)(r / pairs);
+  int i, j;
+  decode_pair(r % pairs, N, i, j);
+  Pt<D> Pi, Pj, Qi, Qj;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    Pi.v[d] = pos_prev[((int64_t)i * K + k) * D + d];
+    Pj.v[d] = pos_prev[((int64_t)j * K + k) * D + d];
+    Qi.v[d] = Pi.v[d] - free_motion(p0[i * D + d], v0[i * D + d], k, h);
+    Qj.v[d] = Pj.v[d] - free_motion(p0[j * D + d], v0[j * D + d], k, h);
+  }
+  const PairGeom<D> g = pair_geom<D>(Pi, Pj);
+  double eta[D], l, dist;
+  pair_row<D>(g, Qi, Qj, R, eta, l, dist);
+  const int64_t o = base + t;
+  w_row[o] = r;
+  wk[o] = k;
+  wi[o] = i;
+  wj[o] = j;
+  double ax = 0.0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    weta[o * D + d] = eta[d];
+    ax += eta[d] * (Qx[(int64_t)k * C + (int64_t)i * D + d] - Qx[(int64_t)k * C + (int64_t)j * D + d]);
+  }
+  wl[o] = l;
+  zc[o] = fmax(ax, l);
+  yc[o] = 0.0;
+}
+
+int scp_launch_add_rows_at(scp_ctx* ctx, int N, int K, int D, int64_t base, int64_t n, const int64_t* rows,
+                           const double* pos_prev, const double* p0, const double* v0, double R, double h, const double* Qx,
+                           int64_t* w_row, int* wk, int* wi, int* wj, double* weta, double* wl, double* zc, double* yc) {
+  const int64_t C = (int64_t)N * D;
+  if (D == 2)
+    hipLaunchKernelGGL(add_rows_at_kernel<2>, dim3(scp_cdiv(n, 256)), dim3(256), 0, ctx->stream, N, K, C, scp_pairs(N), base, n,
+                       rows, pos_prev, p0, v0, R, h, Qx, w_row, wk, wi, wj, weta, wl, zc, yc);
+  else
+    hipLaunchKernelGGL(add_rows_at_kernel<3>, dim3(scp_cdiv(n, 256)), dim3(256), 0, ctx->stream, N, K, C, scp_pairs(N), base, n,
+                       rows, pos_prev, p0, v0, R, h, Qx, w_row, wk, wi, wj, weta, wl, zc, yc);
+  SCP_HIP_CHECK(ctx, hipGetLastError());
+  return SCP_OK;
 }
 
 extern "C" int scp_check_avoidance(scp_ctx* ctx, int N, int K, int D, double R, int64_t q_begin, int64_t q_end,

@@ -857,6 +857,8 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
   qp->persist_off = false;
   qp->persist_skip_solve = false;
   qp->persist_gave_up_total = 0;
+  qp->persist_variant = 0;
+  memset(qp->lim, 0, sizeof(qp->lim));
   qp->persist_fault = 0;
   qp->persist_cap_nW = -1;
   qp->persist_cap = 0;
@@ -936,6 +938,7 @@ extern "C" int scp_qp_set_problem(scp_qp* qp, const double* limits, const double
   SCP_REQUIRE(qp->ctx, limits && space && p0 && v0 && pf && vf, "qp_set_problem: null pointer");
   QP_CHECK(scp_launch_bounds_time_major(qp->ctx, qp->N, qp->K, qp->D, qp->h, limits, space, p0, v0, pf, vf, qp->d.lf,
                                         qp->d.uf));
+  memcpy(qp->lim, limits, sizeof(qp->lim));
   qp->problem_set = true;
   qp->reset_done = false;
   qp->persist_off = false;  // a give-up is a property of the moment (another kernel held the CUs), not of the object
@@ -975,13 +978,18 @@ extern "C" int scp_qp_reset(scp_qp* qp, const double* x0) {
 }
 
 // eta_stride == 0: gathered rows (the public entry point); > 0: eta / l are the arrays of the pairwise pass over the pair
-// range [q_begin, q_begin + nq), gathered by the kernel
+// range [q_begin, q_begin + nq), gathered by the kernel; at != nullptr: no stored rows at all, eta / l are recomputed from
+// the linearisation point
+struct RowsAt {
+  const double *pos_prev, *p0, *v0;
+  double R;
+};
 static int add_rows_impl(scp_qp* qp, int64_t n, const int64_t* rows, const double* eta, const double* l, int64_t eta_stride,
-                         int64_t q_begin, int64_t nq) {
+                         int64_t q_begin, int64_t nq, const RowsAt* at = nullptr) {
   scp_ctx* ctx = qp->ctx;
   if (!qp->reset_done) return scp_fail(ctx, SCP_ERR_STATE, "qp_add_rows: call scp_qp_reset first");
   if (n <= 0) return SCP_OK;
-  SCP_REQUIRE(ctx, rows && eta && l, "qp_add_rows: null pointer");
+  SCP_REQUIRE(ctx, rows && (at || (eta && l)), "qp_add_rows: null pointer");
   if (qp->nW + n > qp->row_cap)
     return scp_fail(ctx, SCP_ERR_CAPACITY, "qp_add_rows: %lld + %lld rows exceed the capacity %lld",
                     (long long)qp->nW, (long long)n, (long long)qp->row_cap);
@@ -994,10 +1002,15 @@ static int add_rows_impl(scp_qp* qp, int64_t n, const int64_t* rows, const doubl
     QP_CHECK(gemm(qp, qp->K, qp->K, 1.0, d.S0, d.x, 0.0, d.HQ + nx));  // (HQ is scratch whenever qx_fresh is false)
     Qx = d.HQ + nx;
   }
-  hipLaunchKernelGGL(add_rows_kernel, grid1(n), dim3(256), 0, ctx->stream, qp->N, qp->D, qp->C, scp_pairs(qp->N),
-                     qp->nW, n, rows, eta, l, eta_stride, q_begin, nq, Qx, d.w_row, d.w_k, d.w_i, d.w_j, d.w_eta, d.w_l, d.zc,
-                     d.yc);
-  QP_LAUNCHED(qp);
+  if (at) {
+    QP_CHECK(scp_launch_add_rows_at(ctx, qp->N, qp->K, qp->D, qp->nW, n, rows, at->pos_prev, at->p0, at->v0, at->R, qp->h, Qx,
+                                    d.w_row, d.w_k, d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc));
+  } else {
+    hipLaunchKernelGGL(add_rows_kernel, grid1(n), dim3(256), 0, ctx->stream, qp->N, qp->D, qp->C, scp_pairs(qp->N),
+                       qp->nW, n, rows, eta, l, eta_stride, q_begin, nq, Qx, d.w_row, d.w_k, d.w_i, d.w_j, d.w_eta, d.w_l,
+                       d.zc, d.yc);
+    QP_LAUNCHED(qp);
+  }
   qp->nW += n;
   qp->persist_cap_nW = -1;
   qp->cg1_ready = false;
@@ -1008,6 +1021,14 @@ static int add_rows_impl(scp_qp* qp, int64_t n, const int64_t* rows, const doubl
 extern "C" int scp_qp_add_rows(scp_qp* qp, int64_t n, const int64_t* rows, const double* w_eta, const double* w_l) {
   if (!qp) return SCP_ERR_INVALID;
   return add_rows_impl(qp, n, rows, w_eta, w_l, 0, 0, 1);
+}
+
+extern "C" int scp_qp_add_rows_at(scp_qp* qp, int64_t n, const int64_t* rows, const double* pos_prev, const double* p0,
+                                  const double* v0, double R) {
+  if (!qp) return SCP_ERR_INVALID;
+  SCP_REQUIRE(qp->ctx, n <= 0 || (pos_prev && p0 && v0), "qp_add_rows_at: null pointer");
+  const RowsAt at{pos_prev, p0, v0, R};
+  return add_rows_impl(qp, n, rows, nullptr, nullptr, 0, 0, 1, &at);
 }
 
 // scp_gather_rows + scp_qp_add_rows in one launch (used by the native SCP loop): eta / l_col are the outputs of
@@ -1058,7 +1079,7 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
       } else if (ran) {
         ++info->persist_launches;
         info->rho_switches_in_kernel += qp->persist_rho_switches;
-        pipes |= 1 << SCP_PIPE_PERSIST;
+        pipes |= 1 << (qp->persist_variant ? SCP_PIPE_PERSIST16 : SCP_PIPE_PERSIST);
         cg_total += it_done - it;
         it = it_done;
         qp->qx_fresh = true;  // the kernel's last check left F x and S0 x exact
@@ -1181,6 +1202,7 @@ extern "C" int scp_qp_clone_state(scp_qp* dst, const scp_qp* src) {
     CP(yc, nw * sizeof(double));
   }
 #undef CP
+  memcpy(dst->lim, src->lim, sizeof(dst->lim));
   dst->nW = src->nW;
   dst->persist_cap_nW = -1;
   dst->rho = src->rho;
@@ -1242,6 +1264,8 @@ extern "C" int scp_qp_peek(scp_qp* qp, const char* name, double* out, int64_t ca
   else if (!strcmp(name, "zc")) { src = d.zc; n = qp->nW; }
   else if (!strcmp(name, "yc")) { src = d.yc; n = qp->nW; }
   else if (!strcmp(name, "x")) { src = d.x; n = nx; }
+  else if (!strcmp(name, "w_eta")) { src = d.w_eta; n = qp->nW * qp->D; }
+  else if (!strcmp(name, "w_l")) { src = d.w_l; n = qp->nW; }
   else if (!strcmp(name, "p")) { src = d.p; n = nx; }
   else if (!strcmp(name, "qp")) { src = d.hpf; n = nx; }
   else return scp_fail(ctx, SCP_ERR_INVALID, "qp_peek: unknown array %s", name);

@@ -86,6 +86,9 @@ struct scp_qp {
   double* h_scal_dev;  // the same memory as the device sees it: the check kernels write their partials straight to it
   unsigned long long check_seq;  // value the flag takes when the current check has finished
   // persistent single-step kernel (scp_qp_persist.hip)
+  double lim[6];                     // {vel, acc, jerk} x {min, max} of the latest scp_qp_set_problem (the lean persistent kernel
+                                     // takes the jerk / acceleration bounds as scalars)
+  int persist_variant;               // of the latest persistent launch: 0 = 8 (4 in 3-D) agents per workgroup, 1 = lean, 16
   int persist_fault;                 // test hook: the next n persistent launches wait for a workgroup that does not exist
   bool persist_off;                  // a launch gave up (workgroups not co-resident): three-launch pipeline until the next
                                      // scp_qp_reset / scp_qp_set_problem re-arms the persistent path

@@ -23,17 +23,16 @@
 //     its partners' cells; the partials alternate between two buffers.
 // Every spin is bounded: a workgroup that times out raises a give-up word, every workgroup then leaves WITHOUT writing
 // state back, and the host repeats the iterations on the three-launch pipeline.
-#include "scp_qp_device.h"
+#include "scp_qp_persist_device.h"
 
+#include <algorithm>
 #include <cerrno>
 #include <chrono>
 
 
 namespace {
 using namespace scpdev;
-
-typedef unsigned long long u64;
-constexpr unsigned SPIN_LIMIT = 1u << 20;
+using namespace scp_persist;
 
 // Developer build (make prof): 100 MHz wall-clock ticks spent per phase, summed over the steps of one launch, middle
 // workgroup, thread 0.
@@ -48,75 +47,6 @@ __device__ unsigned long long scp_persist_clk[16];
 #else
 #define PSTAMP(slot) ((void)0)
 #endif
-
-struct PersistArgs {
-  int K, N, nblk, ent_cap;
-  int it0, max_iter, check_every, rho_interval;  // iterations done so far in this solve; limits; termination / rho periods
-  int64_t C;
-  double rho, rho_c, rho_eq, alpha, h;
-  double eps_abs, eps_rel, eps_prim_inf, rho_tol;  // termination tests (eps_prim_inf <= 0: no certificate; rho_tol <= 0: fixed rho)
-  const double* pMinv;
-  const double* pT;      // packed T = S0 H_f^{-1}
-  const double *lf, *uf;
-  double *zf, *yf, *fx, *x, *Qx, *dyf;
-  u64* cells;       // [K][N][D][2] granules: S0 p of (time step, agent), low / high word, each tagged with the step
-  u64* gpart;       // [2 parities][nblk][4] granules: r.p and sum (eta . d S0 p)^2 of one workgroup
-  u64* gcheck;      // [nblk][18] granules: the nine partial results of a termination check of one workgroup
-  unsigned* give_up;
-  const int *cell_ptr, *ent_code, *w_k, *w_i, *w_j;
-  const double *w_eta, *w_l;
-  double *zc, *yc, *dyc, *gval;
-  unsigned* host_status;  // mapped host words: [0] exit code (EXIT_*), [1] ADMM iterations done when the kernel left
-  double* host_scal;      // mapped host array: the nine check results in the SL_* slots of scp_qp::h_scal
-  u64* host_flag;         // mapped completion word, set to `seq` last
-  u64 seq;
-  unsigned epoch0;        // steps completed by earlier launches (tags never repeat; the buffers start zeroed)
-  // adaptive rho inside the kernel: the rho values whose blocks the host has cached (scp_qp::kkt).  When a check asks for a
-  // new rho that is in this table the kernel switches by itself (operands reloaded, row values recomputed) and goes on;
-  // otherwise it returns EXIT_RHO and the host builds the blocks.  host_status[2] = switches made, *host_rho = rho at exit.
-  double rho_col_scale;
-  double* host_rho;
-  int n_tab;
-  struct RhoSlot {
-    double rho;
-    const double* pMinv;
-    const double* pT;
-  } tab[SCP_KKT_SLOTS_MAX];
-};
-
-// why the kernel returned (host_status[0]); the host re-derives every decision from the nine check results
-enum { EXIT_SOLVED = 1, EXIT_GAVE_UP = 2, EXIT_MAX_ITER = 3, EXIT_INFEASIBLE = 4, EXIT_RHO = 5, EXIT_OVERFLOW = 6 };
-constexpr int NCHK = 9;  // rp, |Ax|, |z|, rd, |Px|, |A^T y|, |dy|, supp (a sum), |A^T dy|  (maxima of non-negative values)
-constexpr int CK_RP = 0, CK_NAX = 1, CK_NZ = 2, CK_RD = 3, CK_NPX = 4, CK_NATY = 5, CK_NDY = 6, CK_SUPP = 7, CK_NATDY = 8;
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-// One double = one 16-byte pair of granules {low word, tag, high word, tag}: ONE write-through store, ONE load (a scalar
-// sc1 store is one fabric write whatever its width: 8-byte stores doubled the hand-off's fabric traffic).  Each 8-byte
-// half carries its own tag, so a torn pair is detected like a late one.  Inline asm because the builtins offer no 16-byte
-// agent-scope access; the asm loads wait for their own data (the compiler does not count them).
-__device__ inline void st_granules(u64* g, unsigned tag, double v) {
-  const u32x4 w = {(unsigned)__double2loint(v), tag, (unsigned)__double2hiint(v), tag};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g), "v"(w) : "memory");
-}
-__device__ inline u32x4 ld_pair(const u64* g) {
-  u32x4 w;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(g) : "memory");
-  return w;
-}
-template <int D>
-__device__ inline void ld_cell(const u64* g, u32x4 (&w)[D]) {  // the D doubles of one cell: D loads in flight, one wait
-  if (D == 2) {
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(w[0]), "=&v"(w[1])
-                 : "v"(g)
-                 : "memory");
-  } else {
-#pragma unroll
-    for (int d = 0; d < D; ++d) w[d] = ld_pair(g + 2 * d);
-  }
-}
-__device__ inline bool pair_ok(const u32x4& w, unsigned tag) { return w[1] == tag && w[3] == tag; }
-__device__ inline double pair_value(const u32x4& w) { return __hiloint2double((int)w[2], (int)w[0]); }
 
 // Agents (= waves) per workgroup.  2-D: 8 waves, two per SIMD, 256 registers each (waves 4-7 double as the T r matrix-core
 // waves).  3-D: FOUR agents (12 of the 16 tile columns), not five -- a wave's 30 columns of fixed-row state need more than 256
@@ -773,13 +703,23 @@ size_t persist_lds_bytes(int K, int D, int cap, int nblk) {
 }  // namespace
 
 // Can the persistent kernel run this QP?  (shape limits; the entry capacity is checked per working set)
+// which kernel runs this shape: 0 = one wave per agent with 8 (3-D: 4) agents per workgroup, 1 = the lean 16-agent kernel
+// (2-D; taken when the blocks of 8 outnumber the CUs, or when settings.persistent == 2 asks for it), -1 = none
+static int persist_variant_for(const scp_qp* qp) {
+  // one workgroup per CU, all resident (grid-wide rendezvous); gpart / gcheck hold SCP_PERSIST_MAX_WG (+1) workgroups
+  const int max_wg = std::min(qp->ctx->n_cu, SCP_PERSIST_MAX_WG);
+  const int apb = persist_apb(qp->D);
+  const bool fits8 = (qp->N + apb - 1) / apb <= max_wg;
+  const bool fits16 = qp->D == 2 && (qp->N + 15) / 16 <= max_wg;
+  if (qp->st.persistent == 2 && fits16) return 1;
+  if (fits8) return 0;
+  return fits16 ? 1 : -1;
+}
+
 bool scp_qp_persist_eligible(const scp_qp* qp) {
   if (!qp->st.persistent || qp->st.cg_iters != 1 || qp->st.use_mfma != 1) return false;
   if (qp->K > 64 || qp->nW <= 0 || qp->persist_off) return false;
-  const int apb = persist_apb(qp->D);
-  const int nblk = (qp->N + apb - 1) / apb;
-  // one workgroup per CU, all resident (grid-wide rendezvous); gpart / gcheck hold SCP_PERSIST_MAX_WG (+1) workgroups
-  return nblk <= qp->ctx->n_cu && nblk <= SCP_PERSIST_MAX_WG;
+  return persist_variant_for(qp) >= 0;
 }
 
 // Run ADMM iterations from iteration count `it0` of the current solve in ONE launch, termination checks included, until
@@ -795,7 +735,10 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   const scp_qp_settings& st = qp->st;
   const int K = qp->K, D = qp->D;
   const int64_t C = qp->C, nx = (int64_t)K * C;
-  const int apb = persist_apb(D);
+  const int variant = persist_variant_for(qp);
+  if (variant < 0) { *ran = 0; return SCP_OK; }
+  const bool lean = variant == 1;
+  const int apb = lean ? 16 : persist_apb(D);
   const int nblk = (qp->N + apb - 1) / apb;
   *ran = 0;
   if (!qp->cg1_ready) {
@@ -808,9 +751,9 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   if (qp->persist_cap_nW == qp->nW) return SCP_OK;  // this working set overflowed before
   {
     const int nb = nblk + 1;  // (+1: the fault-injection hook below may announce one more workgroup)
-    const size_t fixed = persist_lds_bytes(K, D, 0, nb);
-    const size_t per_entry = (size_t)(4 * D + 4) * sizeof(double) + 3 * sizeof(int);
-    const size_t budget_lds = 160 * 1024 - 1024;  // minus the static __shared__ of the kernel (580 B)
+    const size_t fixed = lean ? scp_persist16_lds_bytes(K, 0, nb) : persist_lds_bytes(K, D, 0, nb);
+    const size_t per_entry = lean ? 12 * sizeof(double) + sizeof(int) : (size_t)(4 * D + 4) * sizeof(double) + 3 * sizeof(int);
+    const size_t budget_lds = 160 * 1024 - (lean ? 2048 : 1024);  // minus the static __shared__ of the kernel (580 B / 1.2 KB)
     if (fixed + 64 * per_entry > budget_lds) return SCP_OK;
     qp->persist_cap = (int)((budget_lds - fixed) / per_entry / 64 * 64);
   }
@@ -818,7 +761,8 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   // never complete -- the bounded spins must time out, every workgroup must leave without writing state back, and the
   // host must carry on with the three-launch pipeline
   const int nblk_expected = nblk + (qp->persist_fault > 0 ? 1 : 0);
-  const size_t lds = persist_lds_bytes(K, D, qp->persist_cap, nblk_expected);
+  const size_t lds = lean ? scp_persist16_lds_bytes(K, qp->persist_cap, nblk_expected)
+                          : persist_lds_bytes(K, D, qp->persist_cap, nblk_expected);
   if (lds > 160 * 1024) return SCP_OK;  // too many rows around one block of agents: three-launch pipeline
   const int budget = st.max_iter - it0;  // at most this many steps in this launch
   if (budget <= 0) return SCP_OK;  // nothing to run (the kernel's check would read tags and delta-y of an earlier launch)
@@ -841,6 +785,7 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   a.C = C;
   a.rho = qp->rho; a.rho_c = qp->rho * st.rho_col_scale; a.rho_eq = st.rho_eq_scale; a.alpha = st.alpha; a.h = qp->h;
   a.eps_abs = st.eps_abs; a.eps_rel = st.eps_rel; a.eps_prim_inf = st.eps_prim_inf;
+  a.acc_lo = qp->lim[2]; a.acc_hi = qp->lim[3]; a.jerk_lo = qp->lim[4]; a.jerk_hi = qp->lim[5];
   a.rho_tol = (st.adaptive_rho && st.adaptive_rho_interval > 0) ? st.adaptive_rho_tolerance : 0.0;
   a.pMinv = d.pMinv;
   a.pT = d.pT;
@@ -881,7 +826,11 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
     qp->persist_epoch = 0;
   }
   a.epoch0 = (unsigned)qp->persist_epoch;
-  if (D == 2) {
+  qp->persist_variant = variant;
+  if (lean) {
+    int rc = scp_persist16_launch(ctx, a, nblk, lds);
+    if (rc) return rc;
+  } else if (D == 2) {
     if (lds > 64 * 1024)
       SCP_HIP_CHECK(ctx, scp_raise_lds_limit(ctx->device, reinterpret_cast<const void*>(cg1_persist_kernel<2>), lds));
     hipLaunchKernelGGL(cg1_persist_kernel<2>, dim3(nblk), dim3(64 * persist_apb(2)), lds, s, a);

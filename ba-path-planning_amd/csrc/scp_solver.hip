@@ -16,6 +16,28 @@
 #include <cstdlib>
 #include <vector>
 
+// The problem of the step in flight: one SCP iteration is a sequence of phases (linearise / select, joint-QP round,
+// violations pass, ... , relative step) with an exchange point between any two of them.  scp_solver_step and the SCP loop run
+// the phases back to back over the full pair range; the sharded entry points (scp_solver_shard_*) run the same phases over
+// one rank's pair range and leave the exchanges (an allgather of row ids) to the caller.
+struct StepState {
+  const double *limits, *space, *p0, *v0, *pf, *vf;
+  const double* acc_in;
+  scp_solve_options o;
+  double eps;
+  int64_t q_begin, q_end;
+  bool row_free;
+  int max_iter, used, rounds;
+  int64_t nW, last_added;
+  double max_v;
+  float lin_ms, viol_ms;
+  scp_qp_info info;
+  scp_qp_settings saved;
+  bool active;
+  double t0;            // wall clock at the start of the step
+  double lim_copy[6], space_copy[6];  // sharded steps: the host arrays outlive the call that passed them
+};
+
 struct scp_solver {
   scp_ctx* ctx;
   int N, K, D;
@@ -36,6 +58,7 @@ struct scp_solver {
   // trajectories [N][K][D]
   double *acc, *x, *pos_a, *pos_b, *vel;
   double* pair_pts;  // pinned, 2 D doubles: the two positions of the first violation
+  struct StepState* step;  // the SCP iteration in flight (phases of solve_joint_qp / of the sharded entry points)
 };
 
 namespace {
@@ -107,106 +130,187 @@ int grow_qp(scp_solver* s, int64_t need, bool keep_state, const double* limits, 
   return SCP_OK;
 }
 
-int add_rows_growing(scp_solver* s, int64_t n, int64_t have, bool keep_state, const double* x0, const double* limits,
-                     const double* space, const double* p0, const double* v0, const double* pf, const double* vf) {
-  if (n <= 0) return SCP_OK;
-  int rc = scp_qp_add_rows_from_pass(s->qp, n, s->sel, s->eta, s->l, 0, s->pairs);  // (gathers the rows itself)
-  if (rc != SCP_ERR_CAPACITY) return rc;
-  SV_CHECK(grow_qp(s, have + n, keep_state, limits, space, p0, v0, pf, vf));
-  if (!keep_state) SV_CHECK(scp_qp_reset(s->qp, x0));
-  return scp_qp_add_rows_from_pass(s->qp, n, s->sel, s->eta, s->l, 0, s->pairs);
+// the eta / l planes of the row-writing linearisation (24 B per row: 10 GB at 4096 x 50) exist only once a solve asks for
+// them (options.row_free == 0)
+int ensure_row_planes(scp_solver* s) {
+  if (s->eta && s->l) return SCP_OK;
+  SV_HIP(hipMalloc(&s->eta, (size_t)std::max<int64_t>(s->D * s->stride, 2) * sizeof(double)));
+  SV_HIP(hipMalloc(&s->l, (size_t)std::max<int64_t>(s->rows + (s->rows & 1), 2) * sizeof(double)));
+  return SCP_OK;
 }
 
-// _solve_with_avoidance_constraints (scp.py:399-451): linearise around `acc_in` (whose positions the caller holds in
-// s->pos_a), joint QP with exact constraint generation; result in s->x, its positions in s->pos_b.  eps > 0: termination
-// tolerances of this one QP (the polish step).
-int solve_joint_qp(scp_solver* s, const double* acc_in, const double* limits, const double* space, const double* p0,
-                   const double* v0, const double* pf, const double* vf, const scp_solve_options* o, double eps,
-                   scp_qp_record* rec) {
+// rows[0, n) into the QP: gathered from the stored planes (rows = s->sel of a row-writing pass), or (row_free) recomputed
+// from the linearisation point
+int add_rows_once(scp_solver* s, const int64_t* rows, int64_t n, bool row_free, const double* prev_pos, const double* p0,
+                  const double* v0) {
+  if (row_free) return scp_qp_add_rows_at(s->qp, n, rows, prev_pos, p0, v0, s->R);
+  return scp_qp_add_rows_from_pass(s->qp, n, rows, s->eta, s->l, 0, s->pairs);  // (gathers the rows itself)
+}
+
+int add_rows_growing(scp_solver* s, StepState& t, const int64_t* rows, int64_t n, bool keep_state) {
+  if (n <= 0) return SCP_OK;
+  int rc = add_rows_once(s, rows, n, t.row_free, s->pos_a, t.p0, t.v0);
+  if (rc != SCP_ERR_CAPACITY) return rc;
+  SV_CHECK(grow_qp(s, t.nW + n, keep_state, t.limits, t.space, t.p0, t.v0, t.pf, t.vf));
+  if (!keep_state) SV_CHECK(scp_qp_reset(s->qp, t.acc_in));
+  return add_rows_once(s, rows, n, t.row_free, s->pos_a, t.p0, t.v0);
+}
+
+// the per-QP tolerances (polish) and the per-round iteration budget go into s->st: the caller's settings come back when the
+// step ends -- on EVERY exit path, or an error return would leave a pooled solver object with polish tolerances for all
+// later scenarios
+void step_restore(scp_solver* s, StepState& t) {
+  if (!t.active) return;
+  s->st = t.saved;
+  if (s->qp) (void)scp_qp_update_settings(s->qp, &t.saved);
+  t.active = false;
+}
+struct StepGuard {  // (for the callers that run all phases inside one function)
+  scp_solver* s;
+  StepState& t;
+  ~StepGuard() { step_restore(s, t); }
+};
+
+// phase 1 -- _add_collision_constraints (scp.py:453-557) over the pair range [q_begin, q_end): linearise around `acc_in`,
+// whose positions the caller holds in s->pos_a; the selected rows are s->sel[0, *n_sel) (global ids, ascending)
+int step_linearize(scp_solver* s, StepState& t, const double* acc_in, const double* limits, const double* space,
+                   const double* p0, const double* v0, const double* pf, const double* vf, const scp_solve_options* o,
+                   double eps, int64_t q_begin, int64_t q_end, scp_qp_record* rec, int64_t* n_sel) {
   scp_ctx* ctx = s->ctx;
   const int N = s->N, K = s->K, D = s->D;
-  const size_t nbytes = (size_t)N * K * D * sizeof(double);
-  int max_iter = o->max_iter;
-  // the per-QP tolerances (polish) and the per-round iteration budget go into s->st: put the caller's settings back on EVERY
-  // exit path, or an error return would leave a pooled solver object with polish tolerances for all later scenarios
-  struct RestoreSettings {
-    scp_solver* s;
-    scp_qp_settings saved;
-    ~RestoreSettings() {
-      s->st = saved;
-      if (s->qp) (void)scp_qp_update_settings(s->qp, &saved);
-    }
-  } restore{s, s->st};
+  step_restore(s, t);  // (a step that was abandoned between two phases)
+  t = StepState{};
+  t.limits = limits; t.space = space; t.p0 = p0; t.v0 = v0; t.pf = pf; t.vf = vf;
+  t.acc_in = acc_in; t.o = *o; t.eps = eps; t.q_begin = q_begin; t.q_end = q_end;
+  t.row_free = o->row_free != 0;
+  t.max_iter = o->max_iter;
+  t.saved = s->st;
+  t.active = true;
+  t.t0 = now_s();
   if (eps > 0.0) {
     s->st.eps_abs = s->st.eps_rel = eps;
-    max_iter = std::max(max_iter, 40000);
+    t.max_iter = std::max(t.max_iter, 40000);
   }
-  double* prev_pos = s->pos_a;
+  memset(rec, 0, sizeof(*rec));
+  if (!t.row_free) SV_CHECK(ensure_row_planes(s));
   for (;;) {
-    SV_CHECK(scp_linearize_pairs(ctx, N, K, D, s->R, s->h, 0, s->pairs, prev_pos, p0, v0, s->eta, s->l, o->working_set_margin,
-                                 s->sel, s->sel_cap, s->bitmap, s->stats));
+    if (t.row_free)
+      SV_CHECK(scp_select_pairs(ctx, N, K, D, s->R, q_begin, q_end, s->pos_a, o->working_set_margin, s->sel, s->sel_cap,
+                                s->bitmap, s->stats));
+    else
+      SV_CHECK(scp_linearize_pairs(ctx, N, K, D, s->R, s->h, q_begin, q_end, s->pos_a, p0, v0, s->eta, s->l,
+                                   o->working_set_margin, s->sel, s->sel_cap, s->bitmap, s->stats));
+    if (q_end <= q_begin) {  // an empty shard: nothing ran, nothing was published
+      *n_sel = 0;
+      return SCP_OK;
+    }
     SV_CHECK(read_stats(s, true));
     if ((int64_t)s->h_stats->n_selected <= s->sel_cap) break;
     SV_CHECK(grow_sel(s, (int64_t)s->h_stats->n_selected));
   }
-  float lin_ms = 0.f, viol_ms = 0.f;
-  if (s->pairs > 0) SV_CHECK(scp_ctx_last_pair_ms(ctx, &lin_ms));  // (that kernel has finished: its stats were read)
-  int64_t n = (int64_t)s->h_stats->n_selected;
-  SV_CHECK(scp_qp_update_settings(s->qp, &s->st));
-  SV_CHECK(scp_qp_reset(s->qp, acc_in));
-  SV_CHECK(add_rows_growing(s, n, 0, false, acc_in, limits, space, p0, v0, pf, vf));
-  int64_t nW = n;
+  SV_CHECK(scp_ctx_last_pair_ms(ctx, &t.lin_ms));  // (that kernel has finished: its stats were read)
+  *n_sel = (int64_t)s->h_stats->n_selected;
+  return SCP_OK;
+}
 
-  int used = 0;
-  scp_qp_info info{};
-  memset(rec, 0, sizeof(*rec));
-  if (o->max_rounds < 1) {  // no round runs: the "solution" is the linearisation point
-    SV_HIP(hipMemcpyAsync(s->x, acc_in, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
-    SV_HIP(hipMemcpyAsync(s->pos_b, s->pos_a, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
-  }
-  double max_v = 0.0;
-  int rounds = 0;
-  for (int rnd = 0; rnd < o->max_rounds; ++rnd) {
-    s->st.max_iter = std::max(max_iter - used, 1);
+// phase 2 -- one constraint-generation round of _solve_with_avoidance_constraints (scp.py:399-451): `rows[0, n)` join the
+// working set (first round: the QP is reset to the warm start first), ADMM, solution -> s->x, its positions -> s->pos_b
+int step_qp_round(scp_solver* s, StepState& t, const int64_t* rows, int64_t n, scp_qp_record* rec) {
+  scp_ctx* ctx = s->ctx;
+  const int N = s->N, K = s->K, D = s->D;
+  const bool first = t.rounds == 0;
+  if (first) {
     SV_CHECK(scp_qp_update_settings(s->qp, &s->st));
-    SV_CHECK(scp_qp_solve(s->qp, &info));
-    used += info.iter;
-    rec->iter += info.iter;
-    rec->cg_iters_total += info.cg_iters_total;
-    rec->rho_updates += info.rho_updates;
-    rec->solve_ms += info.solve_ms;
-    rec->pipeline |= info.pipeline;
-    rec->persist_launches += info.persist_launches;
-    rec->persist_gave_up += info.persist_gave_up;
-    rec->rho_switches_in_kernel += info.rho_switches_in_kernel;
-    SV_CHECK(scp_qp_get_solution(s->qp, s->x));
-    SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, s->x, p0, v0, s->pos_b, nullptr));
-    for (;;) {
-      SV_CHECK(scp_collision_violations_at(ctx, N, K, D, s->R, 0, s->pairs, prev_pos, s->pos_b, o->feasibility_tol, s->sel,
-                                           s->sel_cap, s->bitmap, s->stats));
-      SV_CHECK(read_stats(s, true));
-      if ((int64_t)s->h_stats->n_selected <= s->sel_cap) break;
-      SV_CHECK(grow_sel(s, (int64_t)s->h_stats->n_selected));
-    }
-    if (s->pairs > 0) SV_CHECK(scp_ctx_last_pair_ms(ctx, &viol_ms));
-    n = (int64_t)s->h_stats->n_selected;
-    max_v = s->h_stats->max_violation;
-    if (rounds < SCP_MAX_ROUNDS_RECORDED) rec->added[rounds] = n;
-    ++rounds;
-    if (n == 0 || used >= max_iter) break;
-    SV_CHECK(add_rows_growing(s, n, nW, true, nullptr, limits, space, p0, v0, pf, vf));
-    nW += n;
+    SV_CHECK(scp_qp_reset(s->qp, t.acc_in));
   }
-  rec->status_val = info.status_val;
-  rec->working_rows = info.working_rows;
-  rec->r_prim = info.r_prim;
-  rec->r_dual = info.r_dual;
-  rec->rho = info.rho;
-  rec->rounds = rounds;
-  rec->unresolved_rows = n;
-  rec->max_violation = max_v;
-  rec->linearize_ms = lin_ms;
-  rec->violations_ms = viol_ms;
+  SV_CHECK(add_rows_growing(s, t, rows, n, !first));
+  t.nW += n;
+  s->st.max_iter = std::max(t.max_iter - t.used, 1);
+  SV_CHECK(scp_qp_update_settings(s->qp, &s->st));
+  SV_CHECK(scp_qp_solve(s->qp, &t.info));
+  t.used += t.info.iter;
+  rec->iter += t.info.iter;
+  rec->cg_iters_total += t.info.cg_iters_total;
+  rec->rho_updates += t.info.rho_updates;
+  rec->solve_ms += t.info.solve_ms;
+  rec->pipeline |= t.info.pipeline;
+  rec->persist_launches += t.info.persist_launches;
+  rec->persist_gave_up += t.info.persist_gave_up;
+  rec->rho_switches_in_kernel += t.info.rho_switches_in_kernel;
+  SV_CHECK(scp_qp_get_solution(s->qp, s->x));
+  SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, s->x, t.p0, t.v0, s->pos_b, nullptr));
+  return SCP_OK;
+}
+
+// phase 3 -- every row of [q_begin, q_end) checked at the round's solution; the violated rows outside the working set are
+// s->sel[0, *n_new)
+int step_violations(scp_solver* s, StepState& t, int64_t* n_new) {
+  scp_ctx* ctx = s->ctx;
+  *n_new = 0;
+  if (t.q_end <= t.q_begin) {  // no pairs (a single agent, an empty shard): the pass's neutral element
+    t.max_v = -INFINITY;
+    return SCP_OK;
+  }
+  for (;;) {
+    SV_CHECK(scp_collision_violations_at(ctx, s->N, s->K, s->D, s->R, t.q_begin, t.q_end, s->pos_a, s->pos_b,
+                                         t.o.feasibility_tol, s->sel, s->sel_cap, s->bitmap, s->stats));
+    SV_CHECK(read_stats(s, true));
+    if ((int64_t)s->h_stats->n_selected <= s->sel_cap) break;
+    SV_CHECK(grow_sel(s, (int64_t)s->h_stats->n_selected));
+  }
+  SV_CHECK(scp_ctx_last_pair_ms(ctx, &t.viol_ms));
+  *n_new = (int64_t)s->h_stats->n_selected;
+  t.max_v = s->h_stats->max_violation;
+  return SCP_OK;
+}
+
+// bookkeeping after a violations pass that found n_all rows (over all ranks); returns whether another round follows
+bool step_round_done(StepState& t, int64_t n_all, scp_qp_record* rec) {
+  if (t.rounds < SCP_MAX_ROUNDS_RECORDED) rec->added[t.rounds] = n_all;
+  ++t.rounds;
+  t.last_added = n_all;
+  return !(n_all == 0 || t.used >= t.max_iter || t.rounds >= t.o.max_rounds);
+}
+
+void step_finish(scp_solver* s, StepState& t, scp_qp_record* rec) {
+  rec->status_val = t.info.status_val;
+  rec->working_rows = t.info.working_rows;
+  rec->r_prim = t.info.r_prim;
+  rec->r_dual = t.info.r_dual;
+  rec->rho = t.info.rho;
+  rec->rounds = t.rounds;
+  rec->unresolved_rows = t.last_added;
+  rec->max_violation = t.max_v;
+  rec->linearize_ms = t.lin_ms;
+  rec->violations_ms = t.viol_ms;
+  step_restore(s, t);
+}
+
+// _solve_with_avoidance_constraints (scp.py:399-451) on ONE rank: all phases back to back over the full pair range.
+// Linearises around `acc_in` (positions in s->pos_a); result in s->x, its positions in s->pos_b.  eps > 0: termination
+// tolerances of this one QP (the polish step).
+int solve_joint_qp(scp_solver* s, const double* acc_in, const double* limits, const double* space, const double* p0,
+                   const double* v0, const double* pf, const double* vf, const scp_solve_options* o, double eps,
+                   scp_qp_record* rec) {
+  StepState& t = *s->step;
+  StepGuard guard{s, t};
+  const size_t nbytes = (size_t)s->N * s->K * s->D * sizeof(double);
+  int64_t n = 0;
+  SV_CHECK(step_linearize(s, t, acc_in, limits, space, p0, v0, pf, vf, o, eps, 0, s->pairs, rec, &n));
+  if (o->max_rounds < 1) {  // no round runs: the "solution" is the linearisation point
+    SV_CHECK(scp_qp_update_settings(s->qp, &s->st));
+    SV_CHECK(scp_qp_reset(s->qp, acc_in));
+    SV_CHECK(add_rows_growing(s, t, s->sel, n, false));
+    SV_HIP(hipMemcpyAsync(s->x, acc_in, nbytes, hipMemcpyDeviceToDevice, s->ctx->stream));
+    SV_HIP(hipMemcpyAsync(s->pos_b, s->pos_a, nbytes, hipMemcpyDeviceToDevice, s->ctx->stream));
+    t.last_added = n;
+  }
+  for (bool more = o->max_rounds >= 1; more;) {
+    SV_CHECK(step_qp_round(s, t, s->sel, n, rec));
+    SV_CHECK(step_violations(s, t, &n));
+    more = step_round_done(t, n, rec);
+  }
+  step_finish(s, t, rec);
   return SCP_OK;
 }
 
@@ -224,6 +328,8 @@ extern "C" void scp_solve_default_options(scp_solve_options* o) {
   o->feasibility_tol = 1e-6;
   o->polish_eps = 1e-8;
   o->convergence_tolerance = 1.5e-2;  // scp.py:52
+  o->row_free = 1;
+  o->reserved = 0;
 }
 
 extern "C" void scp_solver_destroy(scp_solver* s) {
@@ -235,6 +341,7 @@ extern "C" void scp_solver_destroy(scp_solver* s) {
     if (p) (void)hipFree(p);
   if (s->h_stats) (void)hipHostFree(s->h_stats);
   if (s->pair_pts) (void)hipHostFree(s->pair_pts);
+  delete s->step;
   delete s;
 }
 
@@ -247,6 +354,7 @@ extern "C" int scp_solver_create(scp_ctx* ctx, int N, int K, int D, double h, do
   scp_solver* s = new scp_solver();
   memset(s, 0, sizeof(*s));
   s->ctx = ctx; s->N = N; s->K = K; s->D = D; s->h = h; s->R = R; s->st = *st;
+  s->step = new StepState();
   s->pairs = scp_pairs(N);
   s->rows = (int64_t)K * s->pairs;
   s->stride = scp_eta_stride(K, s->pairs);
@@ -255,9 +363,7 @@ extern "C" int scp_solver_create(scp_ctx* ctx, int N, int K, int D, double h, do
                                    : std::min<int64_t>(s->rows, std::max<int64_t>(8192, (int64_t)32 * N * K));
   if (s->row_cap < 1) s->row_cap = 1;
   const size_t traj = (size_t)N * K * D * sizeof(double);
-  bool ok = hipMalloc(&s->eta, (size_t)std::max<int64_t>(D * s->stride, 2) * sizeof(double)) == hipSuccess &&
-            hipMalloc(&s->l, (size_t)std::max<int64_t>(s->rows + (s->rows & 1), 2) * sizeof(double)) == hipSuccess &&
-            hipMalloc(&s->bitmap, (size_t)std::max<int64_t>((s->rows + 31) / 32, 1) * sizeof(uint32_t)) == hipSuccess &&
+  bool ok = hipMalloc(&s->bitmap, (size_t)std::max<int64_t>((s->rows + 31) / 32, 1) * sizeof(uint32_t)) == hipSuccess &&
             hipMalloc(&s->sel, (size_t)s->sel_cap * sizeof(int64_t)) == hipSuccess &&
             hipMalloc(&s->stats, sizeof(scp_pair_stats)) == hipSuccess &&
             hipHostMalloc(&s->h_stats, sizeof(scp_pair_stats)) == hipSuccess &&
@@ -409,6 +515,116 @@ extern "C" int scp_solver_step(scp_solver* s, const double* limits, const double
   SV_CHECK(solve_joint_qp(s, acc_in, limits, space, p0, v0, pf, vf, o, 0.0, rec));
   double rel[3];
   SV_CHECK(scp_rel_step(ctx, (int64_t)N * K * D, s->x, acc_in, rel));  // scp.py:157-159
+  rec->rel_step = rel[2];
+  SV_HIP(hipMemcpyAsync(acc_out, s->x, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+  SV_HIP(hipStreamSynchronize(ctx->stream));
+  rec->time_sec = now_s() - t0;
+  return SCP_OK;
+}
+
+// ---- one SCP iteration split at its exchange points (one process per GPU, a pair range per rank) --------------------------
+// the row ids the latest selection / violations phase of this rank found (ascending), as many as fit into rows_out
+extern "C" int scp_solver_shard_rows(scp_solver* s, int64_t* rows_out, int64_t rows_cap) {
+  if (!s) return SCP_ERR_INVALID;
+  const int64_t n = s->step->q_end > s->step->q_begin ? std::min<int64_t>((int64_t)s->h_stats->n_selected, rows_cap) : 0;
+  if (n > 0)
+    SV_HIP(hipMemcpyAsync(rows_out, s->sel, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, s->ctx->stream));
+  return SCP_OK;
+}
+
+// begin: bounds, positions of the linearisation point (pos_in: the allgathered per-shard trajectories; NULL: computed here
+// from acc_in), row-free selection over [q_begin, q_end) -> *rows_local (device, ascending global ids), *n_local
+extern "C" int scp_solver_shard_begin(scp_solver* s, const double* limits, const double* space, const double* p0,
+                                      const double* v0, const double* pf, const double* vf, const scp_solve_options* o,
+                                      const double* acc_in, const double* pos_in, int64_t q_begin, int64_t q_end,
+                                      scp_qp_record* rec, int64_t* rows_out, int64_t rows_cap, int64_t* n_local) {
+  if (!s) return SCP_ERR_INVALID;
+  scp_ctx* ctx = s->ctx;
+  SCP_REQUIRE(ctx, limits && space && p0 && v0 && pf && vf && o && acc_in && rec && n_local && (rows_out || rows_cap == 0),
+              "solver_shard_begin: null pointer");
+  SCP_REQUIRE(ctx, o->row_free != 0, "solver_shard_begin: sharded steps are row-free (a rank holds no other rank's rows)");
+  SCP_REQUIRE(ctx, q_begin >= 0 && q_end >= q_begin && q_end <= s->pairs, "solver_shard_begin: bad pair range");
+  const int N = s->N, K = s->K, D = s->D;
+  StepState& t = *s->step;
+  step_restore(s, t);
+  double lim[6], spc[6];
+  memcpy(lim, limits, sizeof(lim));
+  memcpy(spc, space, 2 * D * sizeof(double));
+  SV_CHECK(scp_qp_set_problem(s->qp, limits, space, p0, v0, pf, vf));
+  if (pos_in)
+    SV_HIP(hipMemcpyAsync(s->pos_a, pos_in, (size_t)N * K * D * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  else
+    SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, acc_in, p0, v0, s->pos_a, nullptr));
+  int64_t n = 0;
+  int rc = step_linearize(s, t, acc_in, limits, space, p0, v0, pf, vf, o, 0.0, q_begin, q_end, rec, &n);
+  memcpy(t.lim_copy, lim, sizeof(lim));  // (step_linearize re-initialised the state)
+  memcpy(t.space_copy, spc, sizeof(spc));
+  t.limits = t.lim_copy;
+  t.space = t.space_copy;
+  if (rc != SCP_OK) {
+    step_restore(s, t);
+    return rc;
+  }
+  *n_local = n;
+  return scp_solver_shard_rows(s, rows_out, rows_cap);
+}
+
+// one constraint-generation round: rows[0, n) = the rows ALL ranks found (ascending), into the replicated working set; ADMM
+extern "C" int scp_solver_shard_qp(scp_solver* s, const int64_t* rows, int64_t n, scp_qp_record* rec) {
+  if (!s) return SCP_ERR_INVALID;
+  StepState& t = *s->step;
+  if (!t.active) return scp_fail(s->ctx, SCP_ERR_STATE, "solver_shard_qp: call scp_solver_shard_begin first");
+  SCP_REQUIRE(s->ctx, rec && (rows || n == 0), "solver_shard_qp: null pointer");
+  int rc = step_qp_round(s, t, rows, n, rec);
+  if (rc != SCP_OK) step_restore(s, t);
+  return rc;
+}
+
+// this rank's rows of the violations pass at the round's solution -> *rows_local, *n_local, *max_violation
+extern "C" int scp_solver_shard_violations(scp_solver* s, int64_t* rows_out, int64_t rows_cap, int64_t* n_local,
+                                           double* max_violation) {
+  if (!s) return SCP_ERR_INVALID;
+  StepState& t = *s->step;
+  if (!t.active) return scp_fail(s->ctx, SCP_ERR_STATE, "solver_shard_violations: call scp_solver_shard_begin first");
+  SCP_REQUIRE(s->ctx, n_local && max_violation && (rows_out || rows_cap == 0), "solver_shard_violations: null pointer");
+  int64_t n = 0;
+  t.max_v = -INFINITY;
+  int rc = step_violations(s, t, &n);
+  if (rc != SCP_OK) {
+    step_restore(s, t);
+    return rc;
+  }
+  *n_local = n;
+  *max_violation = t.max_v;
+  return scp_solver_shard_rows(s, rows_out, rows_cap);
+}
+
+// after the exchange: n_all rows were found by all ranks together; *more = another round follows (same decision on every
+// rank: the QP is replicated and deterministic)
+extern "C" int scp_solver_shard_round_done(scp_solver* s, int64_t n_all, double max_violation_all, scp_qp_record* rec,
+                                           int* more) {
+  if (!s) return SCP_ERR_INVALID;
+  StepState& t = *s->step;
+  if (!t.active) return scp_fail(s->ctx, SCP_ERR_STATE, "solver_shard_round_done: no step in flight");
+  SCP_REQUIRE(s->ctx, rec && more, "solver_shard_round_done: null pointer");
+  t.max_v = max_violation_all;
+  *more = step_round_done(t, n_all, rec) ? 1 : 0;
+  return SCP_OK;
+}
+
+// relative step, new accelerations -> acc_out, record completed, the caller's settings restored
+extern "C" int scp_solver_shard_end(scp_solver* s, double* acc_out, scp_qp_record* rec) {
+  if (!s) return SCP_ERR_INVALID;
+  scp_ctx* ctx = s->ctx;
+  StepState& t = *s->step;
+  if (!t.active) return scp_fail(ctx, SCP_ERR_STATE, "solver_shard_end: no step in flight");
+  SCP_REQUIRE(ctx, acc_out && rec, "solver_shard_end: null pointer");
+  StepGuard guard{s, t};
+  const size_t nbytes = (size_t)s->N * s->K * s->D * sizeof(double);
+  double rel[3];
+  SV_CHECK(scp_rel_step(ctx, (int64_t)s->N * s->K * s->D, s->x, t.acc_in, rel));  // scp.py:157-159
+  const double t0 = t.t0;
+  step_finish(s, t, rec);
   rec->rel_step = rel[2];
   SV_HIP(hipMemcpyAsync(acc_out, s->x, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
   SV_HIP(hipStreamSynchronize(ctx->stream));

@@ -58,6 +58,7 @@ class SolveOptions(C.Structure):
         ("max_iterations", C.c_int32), ("max_rounds", C.c_int32), ("max_iter0", C.c_int32), ("max_iter", C.c_int32),
         ("refresh_feasibility", C.c_int32), ("polish", C.c_int32), ("working_set_margin", C.c_double),
         ("feasibility_tol", C.c_double), ("polish_eps", C.c_double), ("convergence_tolerance", C.c_double),
+        ("row_free", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -121,13 +122,14 @@ ABI_VERSION = 4  # SCP_ABI_VERSION of include/scp_hip.h this binding matches (ch
 EXPORTS = [
     "scp_set_host_wait", "scp_abi_version", "scp_ctx_create", "scp_ctx_destroy", "scp_last_error", "scp_ctx_synchronize",
     "scp_ctx_last_pair_ms",
-    "scp_kinematics", "scp_fixed_bounds", "scp_linearize_pairs", "scp_check_avoidance",
+    "scp_kinematics", "scp_fixed_bounds", "scp_linearize_pairs", "scp_select_pairs", "scp_check_avoidance", "scp_qp_add_rows_at",
     "scp_collision_violations", "scp_collision_violations_at", "scp_gather_rows", "scp_rel_step", "scp_qp_default_settings",
     "scp_qp_workspace_bytes", "scp_qp_create", "scp_qp_destroy", "scp_qp_update_settings", "scp_qp_set_problem",
     "scp_qp_reset", "scp_qp_add_rows", "scp_qp_solve", "scp_qp_clone_state", "scp_qp_get_solution",
     "scp_qp_get_duals", "scp_gemm_f64", "scp_qp_peek", "scp_qp_debug_set",
     "scp_solve_default_options", "scp_solver_create", "scp_solver_destroy", "scp_solver_update_settings", "scp_solver_solve",
-    "scp_solver_step",
+    "scp_solver_step", "scp_solver_shard_begin", "scp_solver_shard_rows", "scp_solver_shard_qp", "scp_solver_shard_violations",
+    "scp_solver_shard_round_done", "scp_solver_shard_end",
 ]
 
 
@@ -168,6 +170,7 @@ def load_library():
     lib.scp_kinematics.argtypes = [vp, i32, i32, i32, f64, vp, vp, vp, vp, vp]
     lib.scp_fixed_bounds.argtypes = [vp, i32, i32, i32, f64, pd, pd, vp, vp, vp, vp, vp, vp]
     lib.scp_linearize_pairs.argtypes = [vp, i32, i32, i32, f64, f64, i64, i64, vp, vp, vp, vp, vp, f64, vp, i64, vp, vp]
+    lib.scp_select_pairs.argtypes = [vp, i32, i32, i32, f64, i64, i64, vp, f64, vp, i64, vp, vp]
     lib.scp_check_avoidance.argtypes = [vp, i32, i32, i32, f64, i64, i64, vp, vp]
     lib.scp_collision_violations.argtypes = [vp, i32, i32, i32, f64, i64, i64, vp, vp, vp, vp, vp, f64, vp, i64, vp, vp]
     lib.scp_collision_violations_at.argtypes = [vp, i32, i32, i32, f64, i64, i64, vp, vp, f64, vp, i64, vp, vp]
@@ -184,6 +187,7 @@ def load_library():
     lib.scp_qp_set_problem.argtypes = [vp, pd, pd, vp, vp, vp, vp]
     lib.scp_qp_reset.argtypes = [vp, vp]
     lib.scp_qp_add_rows.argtypes = [vp, i64, vp, vp, vp]
+    lib.scp_qp_add_rows_at.argtypes = [vp, i64, vp, vp, vp, vp, f64]
     lib.scp_qp_solve.argtypes = [vp, C.POINTER(QpInfo)]
     lib.scp_qp_clone_state.argtypes = [vp, vp]
     lib.scp_qp_get_solution.argtypes = [vp, vp]
@@ -200,6 +204,13 @@ def load_library():
     lib.scp_solver_step.argtypes = [vp, pd, pd, vp, vp, vp, vp, C.POINTER(SolveOptions), vp, vp, C.POINTER(QpRecord)]
     lib.scp_solver_solve.argtypes = [vp, pd, pd, vp, vp, vp, vp, C.POINTER(SolveOptions), vp, vp, vp, C.POINTER(SolveResult),
                                      C.POINTER(QpRecord), i32]
+    lib.scp_solver_shard_begin.argtypes = [vp, pd, pd, vp, vp, vp, vp, C.POINTER(SolveOptions), vp, vp, i64, i64,
+                                           C.POINTER(QpRecord), vp, i64, C.POINTER(i64)]
+    lib.scp_solver_shard_rows.argtypes = [vp, vp, i64]
+    lib.scp_solver_shard_qp.argtypes = [vp, vp, i64, C.POINTER(QpRecord)]
+    lib.scp_solver_shard_violations.argtypes = [vp, vp, i64, C.POINTER(i64), C.POINTER(C.c_double)]
+    lib.scp_solver_shard_round_done.argtypes = [vp, i64, f64, C.POINTER(QpRecord), C.POINTER(i32)]
+    lib.scp_solver_shard_end.argtypes = [vp, vp, C.POINTER(QpRecord)]
     _LIB, _LIB_PATH = lib, path
     return lib
 
@@ -336,13 +347,24 @@ class PairPass:
         self.nq = self.q_end - self.q_begin
         self.rows = self.K * self.nq
         self.stride = eta_stride(K, self.nq)
-        self.eta = ctx.empty(max(D * self.stride, 2))
-        self.l = ctx.empty(max(self.rows + (self.rows & 1), 2))
+        self._eta = self._l = None  # the row planes (24 B per row) are allocated when a row-writing pass first needs them
         self.bitmap = torch.zeros(max((self.rows + 31) // 32, 1), dtype=torch.int32, device=ctx.tdev)
         self.sel_cap = int(sel_cap if sel_cap is not None else min(max(self.rows, 1), max(65536, 64 * N * K)))
         self.sel = torch.empty(self.sel_cap, dtype=torch.int64, device=ctx.tdev)
         self.last_linearize_ms = self.last_violations_ms = 0.0
         self.pos_prev = None  # linearisation point of the stored rows (kept for the recomputing violations pass)
+
+    @property
+    def eta(self):
+        if self._eta is None:
+            self._eta = self.ctx.empty(max(self.D * self.stride, 2))
+        return self._eta
+
+    @property
+    def l(self):
+        if self._l is None:
+            self._l = self.ctx.empty(max(self.rows + (self.rows & 1), 2))
+        return self._l
 
     def _grow(self, need):
         torch = _torch()
@@ -357,6 +379,21 @@ class PairPass:
                                               pos_prev.data_ptr(), p0.data_ptr(), v0.data_ptr(), self.eta.data_ptr(),
                                               self.l.data_ptr(), margin, self.sel.data_ptr(), self.sel_cap,
                                               self.bitmap.data_ptr(), c.stats.data_ptr()))
+            min_dist, first, n_sel, _ = c.read_stats()
+            self.last_linearize_ms = c.last_pair_ms() if self.nq > 0 else 0.0
+            if n_sel <= self.sel_cap:
+                self.pos_prev = pos_prev
+                return self.sel[:n_sel].clone(), min_dist, first
+            self._grow(n_sel)
+
+    def select(self, pos_prev, margin):
+        """a5 without the row stream (scp_select_pairs): the same selection, bitmap and a8 statistics as linearize(), eta / l
+        are not written; returns (rows tensor (n,), min_dist, first_violation)."""
+        c = self.ctx
+        while True:
+            c.check(c.lib.scp_select_pairs(c.h, self.N, self.K, self.D, self.R, self.q_begin, self.q_end,
+                                           pos_prev.data_ptr(), margin, self.sel.data_ptr(), self.sel_cap,
+                                           self.bitmap.data_ptr(), c.stats.data_ptr()))
             min_dist, first, n_sel, _ = c.read_stats()
             self.last_linearize_ms = c.last_pair_ms() if self.nq > 0 else 0.0
             if n_sel <= self.sel_cap:
@@ -461,6 +498,15 @@ class QP:
         self.ctx.check(self.ctx.lib.scp_qp_add_rows(self.h_qp, n, rows.data_ptr(), w_eta.data_ptr(), w_l.data_ptr()))
         self.n_rows += n
 
+    def add_rows_at(self, rows, pos_prev, p0, v0, R):
+        """append rows with eta / l recomputed from the linearisation point (scp_qp_add_rows_at)"""
+        n = int(rows.numel())
+        if n == 0:
+            return
+        self.ctx.check(self.ctx.lib.scp_qp_add_rows_at(self.h_qp, n, rows.data_ptr(), pos_prev.data_ptr(), p0.data_ptr(),
+                                                       v0.data_ptr(), float(R)))
+        self.n_rows += n
+
     def take_state_of(self, other: "QP"):
         """Continue `other`'s solve in this (larger) workspace."""
         self.ctx.check(self.ctx.lib.scp_qp_clone_state(self.h_qp, other.h_qp))
@@ -548,3 +594,58 @@ class NativeSolver:
         c.check(c.lib.scp_solver_step(self.h_solver, lp, sp, p0.data_ptr(), v0.data_ptr(), pf.data_ptr(), vf.data_ptr(),
                                       C.byref(options), acc.data_ptr(), out.data_ptr(), C.byref(rec)))
         return out, rec
+
+    # ---- the step split at its exchange points (multi-GPU: one pair range per rank, see scp_hip.h) ----------------------
+    def _rows_buffer(self, need=0):
+        torch = _torch()
+        buf = getattr(self, "_shard_rows", None)
+        if buf is None or buf.numel() < need:
+            cap = max(int(need), 4096, 2 * (buf.numel() if buf is not None else 0))
+            self._shard_rows = buf = torch.empty(cap, dtype=torch.int64, device=self.ctx.tdev)
+        return buf
+
+    def _fetch_rows(self, n):
+        """this rank's row ids of the latest phase as a tensor of its own (the solver's list is reused by the next phase)"""
+        buf = self._rows_buffer()
+        if n > buf.numel():  # the list was longer than the buffer: grow and fetch again
+            buf = self._rows_buffer(n)
+            self.ctx.check(self.ctx.lib.scp_solver_shard_rows(self.h_solver, buf.data_ptr(), buf.numel()))
+        return buf[:n].clone()
+
+    def shard_begin(self, limits, space, p0, v0, pf, vf, options: SolveOptions, acc, pos_in, q_begin, q_end):
+        """-> (QpRecord, this rank's selected row ids (device int64 tensor, ascending))"""
+        c = self.ctx
+        la, lp = _harr(limits)
+        sa, sp = _harr(space)
+        rec = QpRecord()
+        n = C.c_int64()
+        buf = self._rows_buffer()
+        c.check(c.lib.scp_solver_shard_begin(self.h_solver, lp, sp, p0.data_ptr(), v0.data_ptr(), pf.data_ptr(), vf.data_ptr(),
+                                             C.byref(options), acc.data_ptr(), pos_in.data_ptr() if pos_in is not None else None,
+                                             int(q_begin), int(q_end), C.byref(rec), buf.data_ptr(), buf.numel(), C.byref(n)))
+        return rec, self._fetch_rows(int(n.value))
+
+    def shard_qp(self, rows, rec):
+        c = self.ctx
+        n = int(rows.numel())
+        c.check(c.lib.scp_solver_shard_qp(self.h_solver, rows.data_ptr() if n else None, n, C.byref(rec)))
+
+    def shard_violations(self):
+        """-> (this rank's new row ids, max violation over its rows)"""
+        c = self.ctx
+        n, mv = C.c_int64(), C.c_double()
+        buf = self._rows_buffer()
+        c.check(c.lib.scp_solver_shard_violations(self.h_solver, buf.data_ptr(), buf.numel(), C.byref(n), C.byref(mv)))
+        return self._fetch_rows(int(n.value)), float(mv.value)
+
+    def shard_round_done(self, n_all, max_violation_all, rec):
+        more = C.c_int32()
+        self.ctx.check(self.ctx.lib.scp_solver_shard_round_done(self.h_solver, int(n_all), float(max_violation_all),
+                                                                C.byref(rec), C.byref(more)))
+        return bool(more.value)
+
+    def shard_end(self, rec):
+        c = self.ctx
+        out = c.empty(self.N, self.K, self.D)
+        c.check(c.lib.scp_solver_shard_end(self.h_solver, out.data_ptr(), C.byref(rec)))
+        return out

@@ -88,6 +88,40 @@ class Shard:
         all_ids, all_vals = all_ids[keep], all_vals[keep]
         return all_ids.contiguous(), all_vals[:, :D].contiguous(), all_vals[:, D].contiguous()
 
+    def allgather_ids(self, rows, extra=None):
+        """Every rank's row ids (int64, any length) merged in ascending order -- the order a single rank would have found
+        them in, so the replicated QP builds the same working set bit for bit on every world size -- plus, optionally, the
+        max over ranks of one float (`extra`: the violations pass's max violation).  ONE collective: each rank sends
+        [count, bits of extra, ids padded to the capacity every rank agreed on]; a second, longer one only when some rank's
+        list outgrew that capacity.  Returns (ids, max_extra)."""
+        if self.world == 1:
+            return rows, extra
+        dev = rows.device
+        staged = self._host_staged(rows)
+        work = rows.cpu() if staged else rows
+        k = int(work.numel())
+        cap = getattr(self, "_ids_cap", 4096)
+        ex = float("-inf") if extra is None else float(extra)
+        while True:
+            msg = torch.zeros(cap + 2, dtype=torch.int64, device=work.device)
+            msg[0] = k
+            msg[1] = torch.tensor([ex], dtype=torch.float64).view(torch.int64)[0]
+            if k:
+                msg[2:2 + min(k, cap)] = work[: min(k, cap)]
+            out = torch.empty(self.world * (cap + 2), dtype=torch.int64, device=work.device)
+            dist.all_gather_into_tensor(out, msg, group=self.group)
+            out = out.view(self.world, cap + 2)
+            head = out[:, :2].cpu()  # one host read: counts and the extras
+            counts = head[:, 0].tolist()
+            if max(counts) <= cap:
+                break
+            cap = self._ids_cap = 2 * max(counts)  # every rank sees the same counts: the same decision, the same retry
+        self._ids_cap = cap
+        parts = [out[r, 2:2 + c] for r, c in enumerate(counts) if c]
+        ids = torch.sort(torch.cat(parts)).values if parts else work[:0]
+        mx = float(head[:, 1].contiguous().view(torch.float64).max().item())
+        return (ids.to(dev) if staged else ids).contiguous(), (mx if extra is not None else None)
+
     def broadcast(self, tensor, src=0):
         if self.world > 1:
             if self._host_staged(tensor):

@@ -44,6 +44,7 @@ class SCP:
         polish=False,
         polish_eps=1e-8,
         native=True,
+        row_free=True,
         qp_row_capacity=None,
         verbose=True,
         rank=0,
@@ -93,6 +94,10 @@ class SCP:
         self.polish = bool(polish)
         self.polish_eps = float(polish_eps)
         self.native = bool(native)  # drive the SCP loop from C++ (scp_solver_solve) instead of from Python: same calls, same bits
+        # native loop: linearise WITHOUT writing the 24-byte rows of all N(N-1)/2 K pairs (scp_select_pairs) and recompute eta / l
+        # for the selected rows only (scp_qp_add_rows_at); False: scp_linearize_pairs writes every row (what
+        # _add_collision_constraints returns, and what the Python-driven loop does).  Same working rows, same bits.
+        self.row_free = bool(row_free)
         self._native = None
         self._qp_row_capacity = qp_row_capacity  # initial working-set capacity (grows on demand)
         self._qp_overrides = dict(qp_settings or {})
@@ -227,8 +232,19 @@ class SCP:
         while iteration < max_iterations and not converged and not is_feasible:
             self._print(f"SCP Iteration {iteration+1}")
             t_it = time.perf_counter()
-            new_acc = self._solve_with_avoidance_constraints(acc)
-            _, _, rel_step_norm = self._ctx.rel_step(new_acc, acc)  # scp.py:157-159 (no zero guard)
+            if self.native and self.shard.world > 1 and self.row_free:
+                # multi-rank: the iteration natively, split only at its exchange points (same bits as one rank)
+                new_acc, it_info = self.scp_iteration_sharded(acc)
+                rel_step_norm = it_info["rel_step"]
+                if it_info["status_val"] not in (1, 2):  # scp.py:446-447
+                    self._print(f"Warning: OSQP status {it_info['status']}")
+                elif it_info["unresolved_rows"]:
+                    self._print(f"Warning: OSQP status constraint generation stopped with {it_info['unresolved_rows']} "
+                                f"violated collision rows outside the working set (max violation "
+                                f"{it_info['max_violation']:.3e})")
+            else:
+                new_acc = self._solve_with_avoidance_constraints(acc)
+                _, _, rel_step_norm = self._ctx.rel_step(new_acc, acc)  # scp.py:157-159 (no zero guard)
             self._print(rel_step_norm)
             self.last_info["iterations"].append(dict(self._last_qp_info, rel_step=rel_step_norm,
                                                      time_sec=time.perf_counter() - t_it))
@@ -280,18 +296,52 @@ class SCP:
             max_iter0=int(self._qp_overrides.get("max_iter0", self._qp_overrides.get("max_iter", 4000))),
             max_iter=int(self._qp_overrides.get("max_iter", 10000)), refresh_feasibility=int(self.refresh_feasibility),
             polish=int(self.polish), working_set_margin=self.working_set_margin, feasibility_tol=self.feasibility_tol,
-            polish_eps=self.polish_eps, convergence_tolerance=self.convergence_tolerance)
+            polish_eps=self.polish_eps, convergence_tolerance=self.convergence_tolerance, row_free=int(self.row_free))
 
     def scp_iteration(self, accelerations):
         """ONE pass of the SCP loop body (scp.py:152-166) in one library call (scp_solver_step): linearise around
         `accelerations` (device (N, K, D)), joint QP, relative step.  Returns (new accelerations, info dict).  This is what
         bench.py times; generate_trajectories runs the same code in its native loop."""
         if self.shard.world != 1:
-            raise RuntimeError("scp_iteration: single-rank only (the sharded loop is driven from Python)")
+            return self.scp_iteration_sharded(accelerations)
         nat = self._ensure_native()
         p0, v0, pf, vf = self._states()
         new, rec = nat.step(self._limits(), self._space(), p0, v0, pf, vf, self._native_options(),
                             self._to_device_acc(accelerations))
+        info = dict(rec.as_dict(), rel_step=float(rec.rel_step), time_sec=float(rec.time_sec))
+        self._last_qp_info = info
+        return new, info
+
+    def scp_iteration_sharded(self, accelerations, exchange_positions=True):
+        """The same iteration with the O(N^2 K) passes sharded over the ranks (scp_solver_shard_*): every rank selects /
+        checks the pairs of ITS range, the row ids are allgathered (sorted: the single-rank order), the joint QP is
+        replicated -- deterministic, so every rank holds the same bits and nothing is broadcast.  With one rank this is
+        scp_solver_step phase by phase (same result, bit for bit); the exchanges are the only difference otherwise.
+
+        exchange_positions: the per-shard trajectories of the linearisation point are computed by the rank that owns the
+        agents and allgathered (one collective per SCP iteration, the north-star layout); False: every rank integrates
+        all agents itself (N K^2 flops, cheaper than the collective below ~10^4 agents)."""
+        nat = self._ensure_native()
+        p0, v0, pf, vf = self._states()
+        acc = self._to_device_acc(accelerations)
+        opts = self._native_options()
+        if not opts.row_free:
+            raise ValueError("the sharded step is row-free: a rank does not hold the rows of another rank's pairs")
+        pos_in = None
+        if exchange_positions and self.shard.world > 1:
+            pos_in, _ = self._kinematics(acc, want_vel=False)  # agent-sharded kinematics + allgather of the trajectories
+        q0, q1 = self.shard.pair_range()
+        rec, rows = nat.shard_begin(self._limits(), self._space(), p0, v0, pf, vf, opts, acc, pos_in, q0, q1)
+        rows, _ = self.shard.allgather_ids(rows)
+        more = opts.max_rounds >= 1
+        if not more:
+            raise ValueError("the sharded step needs max_rounds >= 1")
+        while more:
+            nat.shard_qp(rows, rec)
+            rows, max_v = nat.shard_violations()
+            rows, max_v = self.shard.allgather_ids(rows, extra=max_v)
+            more = nat.shard_round_done(int(rows.numel()), max_v, rec)
+        new = nat.shard_end(rec)
         info = dict(rec.as_dict(), rel_step=float(rec.rel_step), time_sec=float(rec.time_sec))
         self._last_qp_info = info
         return new, info

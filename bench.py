@@ -130,15 +130,20 @@ def main():
         if world == 1:  # the loop body as ONE library call (scp_solver_step): what generate_trajectories runs per iteration
             new, info = solver.scp_iteration(acc0)
             return new, info["rel_step"], info["linearize_ms"], info["violations_ms"]
-        new = solver._solve_with_avoidance_constraints(acc0)  # sharded: the same calls driven from Python + collectives
-        rel = solver._ctx.rel_step(new, acc0)[2]
-        return new, rel, pp.last_linearize_ms, pp.last_violations_ms
+        # sharded: the same phases natively (scp_solver_shard_*), split only at the exchanges (allgather of the per-shard
+        # trajectories once per iteration, of the selected / violated row ids once per constraint-generation round)
+        new, info = solver.scp_iteration_sharded(acc0)
+        return new, info["rel_step"], info["linearize_ms"], info["violations_ms"]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The timed step linearises with the ROW-WRITING kernel (scp_linearize_pairs: the roofline kernel, 24 B per row to HBM --
+    # what SCP._add_collision_constraints returns); the row-free step (scp_select_pairs + recomputed working rows: the default
+    # of generate_trajectories, same bits) is timed right after it and reported beside it.
+    solver.row_free = world > 1  # (a sharded step is row-free: a rank holds no other rank's rows)
     for _ in range(args.warmup):
         step()
     lin_ms, viol_ms, infos = [], [], []
@@ -156,10 +161,36 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    row_free = None
+    if world == 1:
+        solver.row_free = True
+        for _ in range(max(args.warmup, 1)):
+            step()
+        sel_ms = []
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            _, rel_rf, lms, _ = step()
+            sel_ms.append(lms)
+        torch.cuda.synchronize()
+        dt_rf = time.perf_counter() - t1
+        rf_info = dict(solver._last_qp_info)
+        row_free = {
+            "ms_per_step": dt_rf / args.steps * 1e3, "value": args.steps / dt_rf, "unit": "SCP iterations/s",
+            "select_pass_avg_ms": float(np.mean(sel_ms)),
+            "same_result": bool(rel_rf == infos[-1]["rel_step"] and rf_info["iter"] == infos[-1]["iter"]
+                                and rf_info["working_rows"] == infos[-1]["working_rows"]),
+            "note": "the same step with pair_pass_kernel<D,SELECT> (no eta / l planes written or allocated) and the working "
+                    "rows recomputed from the linearisation point: the default of generate_trajectories, bit-identical",
+        }
+        solver.row_free = False
+
     # HBM traffic of that kernel from the committed PMC passes (profiles/README.md): same workload only, and only while
     # the kernel source is the one the counters were collected on (otherwise null: a stale figure helps nobody)
     traffic, traffic_note, viol_traffic = None, None, None
-    tpath = os.path.join(ROOT, "profiles", "r02_pairwise_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r03_pairwise_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r02_pairwise_traffic.json")
     if world == 1 and (N, K, D) == (1024, 50, 2) and os.path.exists(tpath):
         import hashlib
 
@@ -176,6 +207,8 @@ def main():
     # roofline of the dominant pairwise kernel (per rank: its own shard of rows)
     rows = pp.rows
     alg_bytes = rows * 8 * (D + 1) + 2 * N * K * D * 8  # 24 B/row (D=2) + the two trajectory arrays
+    if world > 1:  # the sharded step runs the row-free selection pass: its algorithmic traffic is the trajectory array only
+        alg_bytes = N * K * D * 8
     avg_ms = float(np.mean(lin_ms)) if lin_ms else float("nan")
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     out = {
@@ -200,7 +233,10 @@ def main():
             "rel_step": infos[-1]["rel_step"],
         },
         "roofline": {
-            "kernel": "pair_pass_kernel<D,LINEARIZE> (scp_linearize_pairs)",
+            "kernel": ("pair_pass_kernel<D,LINEARIZE> (scp_linearize_pairs)" if world == 1 else
+                       "pair_pass_kernel<D,SELECT> (scp_select_pairs over this rank's pair range: the row-free pass writes no "
+                       "rows, its only HBM traffic is the trajectory array -- fp64 VALU / LDS bound, frac is not a target here; "
+                       "the HBM-bound row-writing kernel is measured by the 1-GPU line)"),
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "bytes_per_launch": alg_bytes, "rows_per_launch": rows, "avg_launch_ms": avg_ms,
             # the rest of the step, for scale: the violations pass recomputes its rows (no HBM stream: fp64 VALU / LDS
@@ -222,6 +258,9 @@ def main():
                            "frac": alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
         },
     }
+    out["row_free_step"] = row_free
+    out["config"]["qp"]["pipeline"] = infos[-1].get("pipeline")
+    out["config"]["qp"]["persist_gave_up"] = infos[-1].get("persist_gave_up")
     if traffic_note:
         out["roofline"]["traffic_note"] = traffic_note
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

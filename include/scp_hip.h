@@ -76,8 +76,10 @@ typedef struct scp_qp_settings {
                                     evaluated at every termination check; <= 0 disables it */
   int32_t persistent;            /* 1: cg_iters == 1, K <= 64 and at most one block of 16/D agents per compute unit run
                                     all ADMM steps between two termination checks in ONE persistent launch (solver state
-                                    on chip, two grid-wide exchanges per step); 0: three launches per step.  Same
-                                    arithmetic up to the summation order of the line-search partials */
+                                    on chip, two grid-wide exchanges per step) -- beyond that, 2-D problems of up to 16 agents
+                                    per compute unit (4096) run the lean 16-agent form of the kernel; 2: the lean form
+                                    whenever it fits (tests); 0: three launches per step.  Same arithmetic up to the
+                                    association of sums */
 } scp_qp_settings;
 
 /* [host] result of scp_qp_solve */
@@ -156,6 +158,13 @@ int scp_linearize_pairs(scp_ctx* ctx, int N, int K, int D, double R, double h, i
                         double* l_out, double margin, int64_t* sel_rows, int64_t sel_cap, uint32_t* sel_bitmap,
                         scp_pair_stats* stats);
 
+/* The same pass WITHOUT the row stream ("row-free" linearisation): identical distances, selection test (dist - R < margin),
+ * sel_rows / sel_bitmap / stats as scp_linearize_pairs, but eta / l are not written (24 B per row: 630 MB at 1024 x 50,
+ * 10 GB at 4096 x 50, of which the loop consumes the ~0.05 % selected rows).  The consumer recomputes the selected rows
+ * with scp_qp_add_rows_at; scp_collision_violations_at never needed the stored rows. */
+int scp_select_pairs(scp_ctx* ctx, int N, int K, int D, double R, int64_t q_begin, int64_t q_end, const double* pos_prev,
+                     double margin, int64_t* sel_rows, int64_t sel_cap, uint32_t* sel_bitmap, scp_pair_stats* stats);
+
 /* ---- a8: SCP._fast_check_avoidance_constraints (scp.py:597-615) --------------------------------------
  * stats->first_violation = first row (k -> i -> j order) with ||p_i - p_j|| < R - 0.01, stats->min_dist. */
 int scp_check_avoidance(scp_ctx* ctx, int N, int K, int D, double R, int64_t q_begin, int64_t q_end,
@@ -209,6 +218,10 @@ int scp_qp_set_problem(scp_qp* qp, const double* limits /*[host]*/, const double
 int scp_qp_reset(scp_qp* qp, const double* x0);
 /* append working rows (global ids; eta AoS [n][D]; lower bounds); z = max(A x, l), y = 0 */
 int scp_qp_add_rows(scp_qp* qp, int64_t n, const int64_t* rows, const double* w_eta, const double* w_l);
+/* append working rows with eta / l recomputed from the linearisation point pos_prev ([N][K][D]) by the arithmetic of
+ * scp_linearize_pairs (bit-identical to gathering its stored rows); p0, v0 [N][D]; R = min_distance */
+int scp_qp_add_rows_at(scp_qp* qp, int64_t n, const int64_t* rows, const double* pos_prev, const double* p0,
+                       const double* v0, double R);
 int scp_qp_solve(scp_qp* qp, scp_qp_info* info /*[host]*/);
 /* Move a QP to a larger workspace: dst (same N, K, D, h; row_capacity >= src's working rows) takes over the
  * problem bounds, iterate, duals, working set and rho of src, so a solve can continue after its working set outgrew
@@ -238,6 +251,10 @@ typedef struct scp_solve_options {
   double feasibility_tol;       /* 1e-6 */
   double polish_eps;            /* 1e-8 */
   double convergence_tolerance; /* 1.5e-2 (scp.py:52) */
+  int32_t row_free;             /* 1: linearise with scp_select_pairs + scp_qp_add_rows_at (no eta / l planes are written
+                                   or allocated); 0: scp_linearize_pairs writes all rows and the working rows are gathered
+                                   from them.  Same working rows, same bits either way */
+  int32_t reserved;
 } scp_solve_options;
 
 #define SCP_MAX_ROUNDS_RECORDED 24
@@ -286,6 +303,32 @@ int scp_solver_solve(scp_solver* s, const double* limits, const double* space, c
 int scp_solver_step(scp_solver* s, const double* limits, const double* space, const double* p0, const double* v0,
                     const double* pf, const double* vf, const scp_solve_options* o, const double* acc_in, double* acc_out,
                     scp_qp_record* rec);
+
+/* ---- the same iteration split at its exchange points: agents / pairs sharded over the GPUs of a node, one process per GPU ---
+ * Every rank holds the whole (N, K, D) problem and calls, per SCP iteration,
+ *   scp_solver_shard_begin       bounds, positions of the linearisation point (pos_in = the allgathered per-shard trajectories,
+ *                                or NULL: computed from acc_in), row-free selection over ITS pair range -> its row ids
+ *   [exchange: allgather of the ids, sorted ascending -- the only data that crosses ranks]
+ *   scp_solver_shard_qp          the gathered rows join the REPLICATED working set (eta / l recomputed locally: every rank
+ *                                has the linearisation point), ADMM on the joint QP: deterministic, the same bits on every rank
+ *   scp_solver_shard_violations  every row of its pair range checked at the solution -> its new row ids, max violation
+ *   [exchange: allgather of the ids, max of the violations]
+ *   scp_solver_shard_round_done  *more = another round (-> shard_qp with the new rows) or not
+ *   scp_solver_shard_end         relative step, acc_out, the record
+ * which are the phases scp_solver_step runs back to back over the full pair range: a world of one rank that skips the
+ * exchanges reproduces scp_solver_step bit for bit, and so does any world size (sorted ids = the single-rank row order).
+ * rows_out (device, capacity rows_cap) receives this rank's ids, *n_local [host] their number; if n_local > rows_cap only the
+ * first rows_cap were copied: fetch them again with scp_solver_shard_rows into a longer list.  rec [host] accumulates. */
+int scp_solver_shard_begin(scp_solver* s, const double* limits, const double* space, const double* p0, const double* v0,
+                           const double* pf, const double* vf, const scp_solve_options* o, const double* acc_in,
+                           const double* pos_in, int64_t q_begin, int64_t q_end, scp_qp_record* rec,
+                           int64_t* rows_out, int64_t rows_cap, int64_t* n_local);
+int scp_solver_shard_rows(scp_solver* s, int64_t* rows_out, int64_t rows_cap);
+int scp_solver_shard_qp(scp_solver* s, const int64_t* rows, int64_t n, scp_qp_record* rec);
+int scp_solver_shard_violations(scp_solver* s, int64_t* rows_out, int64_t rows_cap, int64_t* n_local,
+                                double* max_violation);
+int scp_solver_shard_round_done(scp_solver* s, int64_t n_all, double max_violation_all, scp_qp_record* rec, int* more);
+int scp_solver_shard_end(scp_solver* s, double* acc_out, scp_qp_record* rec);
 
 /* ---- test hooks (dense K-dimension products used by the QP; exercised by tests/test_kernels_gpu.py::test_gemm_f64) ------
  * Y[R][C] = alpha * A[R][M] X[M][C] + beta * Y, row-major, device pointers. */

@@ -150,6 +150,44 @@ def test_linearize_pair_range_shards(ctx, N, K, cuts):
     np.testing.assert_array_equal(np.sort(np.concatenate(got)), np.nonzero(dist_o - prob.R < 0.7)[0])
 
 
+@pytest.mark.parametrize("N,K,D,seed,cut", [(2, 5, 2, 1, None), (33, 21, 3, 3, None), (96, 50, 2, 4, None), (65, 50, 3, 5, None),
+                                             (300, 7, 2, 7, None), (700, 10, 2, 10, None), (130, 17, 2, 6, (1000, 6001))])
+def test_row_free_linearisation_is_bit_identical(ctx, N, K, D, seed, cut):
+    """scp_select_pairs + scp_qp_add_rows_at (the row-free loop: no eta / l planes) against scp_linearize_pairs + gather +
+    scp_qp_add_rows: the same selected rows, bitmap and a8 statistics, and BITWISE the same working rows (eta, l, z_c)."""
+    import torch
+    from path_planning import _hip
+
+    prob, acc = synth(N, K, D, seed)
+    pos, _ = so.kinematics(prob, acc)
+    q0, q1 = cut if cut else (0, prob.pairs)
+    pos_t, p0, v0 = ctx.tensor(pos), ctx.tensor(prob.p0), ctx.tensor(prob.v0)
+    a = _hip.PairPass(ctx, N, K, D, prob.R, prob.h, q0, q1)
+    b = _hip.PairPass(ctx, N, K, D, prob.R, prob.h, q0, q1)
+    rows_a, md_a, fv_a = a.linearize(pos_t, p0, v0, 0.6)
+    rows_b, md_b, fv_b = b.select(pos_t, 0.6)
+    assert b._eta is None and b._l is None  # nothing was allocated, nothing written
+    assert torch.equal(rows_a, rows_b) and md_a == md_b and fv_a == fv_b
+    assert torch.equal(a.bitmap, b.bitmap)
+    if rows_a.numel() == 0:
+        return
+    space = np.concatenate([prob.pos_min, prob.pos_max])
+    x0 = ctx.tensor(acc.reshape(N, K, D))
+    got = {}
+    for mode in ("gather", "at"):
+        qp = _hip.QP(ctx, N, K, D, prob.h, _hip.default_settings(), row_capacity=int(rows_a.numel()))
+        qp.set_problem(LIMITS, space, p0, v0, ctx.tensor(prob.pf), ctx.tensor(prob.vf))
+        qp.reset(x0)
+        if mode == "gather":
+            qp.add_rows(rows_a, *a.gather(rows_a))
+        else:
+            qp.add_rows_at(rows_b, pos_t, p0, v0, prob.R)
+        got[mode] = {k: qp.peek(k).cpu().numpy() for k in ("w_eta", "w_l", "zc", "yc")}
+        qp.close()
+    for k in got["gather"]:
+        np.testing.assert_array_equal(got["at"][k], got["gather"][k], err_msg=k)
+
+
 def test_degenerate_pair(ctx):
     from path_planning import _hip
 
@@ -158,9 +196,20 @@ def test_degenerate_pair(ctx):
     pos, _ = so.kinematics(prob, np.zeros(prob.n))
     eta_o, l_o, _ = so.linearize_pairs(prob, pos)
     pp = _hip.PairPass(ctx, 3, prob.K, 2, prob.R, prob.h)
-    pp.linearize(ctx.tensor(pos), ctx.tensor(prob.p0), ctx.tensor(prob.v0), 0.5)
+    rows, _, _ = pp.linearize(ctx.tensor(pos), ctx.tensor(prob.p0), ctx.tensor(prob.v0), 0.5)
     np.testing.assert_allclose(pp.eta_rows().cpu().numpy(), eta_o, rtol=0, atol=1e-15)
     np.testing.assert_allclose(pp.l_rows().cpu().numpy(), l_o, rtol=0, atol=1e-15)
+    # the row-free pass applies the same degenerate rule (dist := 1, eta = e_0): same selection, same recomputed rows
+    rows2, _, _ = _hip.PairPass(ctx, 3, prob.K, 2, prob.R, prob.h).select(ctx.tensor(pos), 0.5)
+    np.testing.assert_array_equal(rows2.cpu().numpy(), rows.cpu().numpy())
+    qp = _hip.QP(ctx, 3, prob.K, 2, prob.h, _hip.default_settings(), row_capacity=64)
+    qp.set_problem(LIMITS, np.array([0.0, 0, 20, 20]), ctx.tensor(prob.p0), ctx.tensor(prob.v0), ctx.tensor(prob.pf), ctx.tensor(prob.vf))
+    qp.reset(None)
+    qp.add_rows_at(rows2, ctx.tensor(pos), ctx.tensor(prob.p0), ctx.tensor(prob.v0), prob.R)
+    r = rows.cpu().numpy()
+    np.testing.assert_array_equal(qp.peek("w_eta").cpu().numpy().reshape(-1, 2), pp.eta_rows().cpu().numpy()[r])
+    np.testing.assert_array_equal(qp.peek("w_l").cpu().numpy(), pp.l_rows().cpu().numpy()[r])
+    qp.close()
 
 
 @pytest.mark.parametrize("recompute", [True, False])

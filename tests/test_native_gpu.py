@@ -43,10 +43,15 @@ def test_native_loop_is_bit_identical(case):
     else:
         n, T, h = 1, 2.0, 0.2
         p0, pf, space = np.array([[3.0, 3.0]]), np.array([[3.05, 2.95]]), [0, 0, 20, 20]
-    a, ta = solve(True, n, T, h, space, p0, pf, dim=dim, **kw)
-    b, tb = solve(False, n, T, h, space, p0, pf, dim=dim, **kw)
+    a, ta = solve(True, n, T, h, space, p0, pf, dim=dim, **kw)  # native loop, row-free linearisation (the default)
+    b, tb = solve(False, n, T, h, space, p0, pf, dim=dim, **kw)  # Python-driven loop: every row written, working rows gathered
+    c, tc = solve(True, n, T, h, space, p0, pf, dim=dim, row_free=False, **kw)  # native loop on the row-writing kernel
     for key in ("positions", "velocities", "accelerations"):
         np.testing.assert_array_equal(ta[key], tb[key])
+        np.testing.assert_array_equal(ta[key], tc[key])
+    for ra, rc in zip(a.last_info["iterations"], c.last_info["iterations"]):
+        same_records(ra, rc)
+        assert ra["rel_step"] == rc["rel_step"] and ra["pipeline"] == rc["pipeline"]
     ia, ib = a.last_info, b.last_info
     assert (ia["n_iterations"], ia["converged"], ia["initially_feasible"]) == (ib["n_iterations"], ib["converged"], ib["initially_feasible"])
     assert ia["qp0"]["iter"] == ib["qp0"]["iter"] and ia["qp0"]["status_val"] == ib["qp0"]["status_val"]
@@ -101,9 +106,39 @@ def test_scp_iteration_is_the_python_loop_body():
     ref = s._solve_with_avoidance_constraints(acc0)
     ref_info = dict(s._last_qp_info)
     ref_rel = s._ctx.rel_step(ref, acc0)[2]
-    for _ in range(2):  # repeatable from the same input (the solver object carries no state from call to call)
+    for rep in range(3):  # repeatable from the same input (the solver object carries no state from call to call);
+        s.row_free = rep != 2  # row-free linearisation (default) and the row-writing kernel give the same bits
         new, info = s.scp_iteration(acc0)
         np.testing.assert_array_equal(new.cpu().numpy(), ref.cpu().numpy())
         same_records(info, ref_info)
         assert info["rel_step"] == ref_rel
         assert 0.0 < info["linearize_ms"] < 5.0 and 0.0 < info["violations_ms"] < 5.0 and info["time_sec"] > 0
+
+
+@pytest.mark.parametrize("n,dim,seed", [(64, 2, 64000), (27, 3, 17), (1, 2, 0)])
+def test_sharded_step_with_one_rank_is_scp_solver_step(n, dim, seed):
+    """scp_solver_shard_begin / _qp / _violations / _round_done / _end are the phases scp_solver_step runs back to back: driven
+    one by one over the full pair range (a world of one rank, no exchange) they give the same accelerations and the same
+    record, bit for bit; a second call shows that no state leaks from step to step."""
+    from path_planning.scenarios.position_generator import generate_grid_swap
+    from path_planning.solvers.scp import SCP
+
+    if n == 1:
+        p0, pf, space, T = np.array([[3.0, 3.0]]), np.array([[3.05, 2.95]]), [0, 0, 20, 20], 2.0
+    else:
+        p0, pf, space = generate_grid_swap(n, seed=seed, dim=dim)
+        T = 10.0
+    s = SCP(n, T, 0.2, 0.8, space, dim=dim, verbose=False)
+    s.set_initial_states(p0)
+    s.set_final_states(pf)
+    s._precompute_constraint_matrices()
+    acc0 = s._solve_initial_trajectory()
+    ref, ref_info = s.scp_iteration(acc0)
+    for _ in range(2):
+        new, info = s.scp_iteration_sharded(acc0)
+        np.testing.assert_array_equal(new.cpu().numpy(), ref.cpu().numpy())
+        same_records(info, ref_info)
+        assert info["rel_step"] == ref_info["rel_step"] and info["pipeline"] == ref_info["pipeline"]
+    s.row_free = False
+    with pytest.raises(ValueError):
+        s.scp_iteration_sharded(acc0)

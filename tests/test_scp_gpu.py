@@ -210,12 +210,17 @@ def _two_rank_worker(rank, world, port, out_dir):
     from path_planning.solvers.scp import SCP
 
     p0, pf, space = generate_grid_swap(40, seed=11)
-    s = SCP(40, 10.0, 0.2, 0.8, space, verbose=False, device=0, rank=rank, world_size=world)
-    s.set_initial_states(p0)
-    s.set_final_states(pf)
-    traj = s.generate_trajectories(max_iterations=3)
-    np.save(os.path.join(out_dir, f"pos_{rank}.npy"), traj["positions"])
-    np.save(os.path.join(out_dir, f"its_{rank}.npy"), np.array([i["iter"] for i in s.last_info["iterations"]]))
+    for tag, native in (("", True), ("py_", False)):
+        # native: the iteration natively, split at its exchange points (scp_solver_shard_*: ids only cross ranks);
+        # Python-driven: every call from Python, compact rows (ids + eta + l) exchanged, rank 0's solution broadcast
+        s = SCP(40, 10.0, 0.2, 0.8, space, verbose=False, device=0, rank=rank, world_size=world, native=native)
+        s.set_initial_states(p0)
+        s.set_final_states(pf)
+        traj = s.generate_trajectories(max_iterations=3)
+        np.save(os.path.join(out_dir, f"{tag}pos_{rank}.npy"), traj["positions"])
+        np.save(os.path.join(out_dir, f"{tag}its_{rank}.npy"), np.array([i["iter"] for i in s.last_info["iterations"]]))
+        if native:
+            np.save(os.path.join(out_dir, f"rows_{rank}.npy"), np.array([i["working_rows"] for i in s.last_info["iterations"]]))
     dist.destroy_process_group()
 
 
@@ -234,7 +239,14 @@ def test_scp_two_ranks_share_one_gpu(tmp_path):
     p0, pf, space = generate_grid_swap(40, seed=11)
     s, traj = solve_gpu(40, 10.0, 0.2, 0.8, space, p0, pf, max_iterations=3)
     assert [i["iter"] for i in s.last_info["iterations"]] == np.load(tmp_path / "its_0.npy").tolist()
-    np.testing.assert_allclose(a, traj["positions"], rtol=0, atol=1e-8)
+    assert [i["working_rows"] for i in s.last_info["iterations"]] == np.load(tmp_path / "rows_0.npy").tolist()
+    # the native sharded step merges the ranks' row ids in ascending order = the single-rank working set, and the replicated
+    # QP is deterministic: two ranks reproduce the one-rank solve BIT FOR BIT
+    np.testing.assert_array_equal(a, traj["positions"])
+    pa, pb = np.load(tmp_path / "py_pos_0.npy"), np.load(tmp_path / "py_pos_1.npy")
+    np.testing.assert_array_equal(pa, pb)
+    assert np.load(tmp_path / "py_its_0.npy").tolist() == np.load(tmp_path / "its_0.npy").tolist()
+    np.testing.assert_allclose(pa, traj["positions"], rtol=0, atol=1e-8)
 
 
 @pytest.mark.parametrize("n,T,h,dim", [(1, 2.0, 0.2, 2), (2, 0.8, 0.2, 2), (1, 2.0, 0.5, 3), (3, 1.0, 0.5, 3)])

@@ -52,6 +52,16 @@ def _worker(rank, world, port, N, K, out_dir):
     assert np.array_equal(np.sort(rows), sel)
     assert np.array_equal(w_eta.numpy(), eta[rows]) and np.array_equal(w_l.numpy(), l[rows])
 
+    # the row-free exchange: ids only, merged in ascending order (the single-rank order) + the max of one float, ONE collective;
+    # a rank whose list outgrows the agreed capacity makes every rank repeat it with a longer message
+    ids, mx = sh.allgather_ids(torch.from_numpy(np.sort(mine).astype(np.int64)), extra=0.25 * (rank + 1))
+    assert np.array_equal(ids.numpy(), sel) and mx == 0.25 * world
+    sh._ids_cap = 2
+    ids2, none = sh.allgather_ids(torch.from_numpy(np.sort(mine).astype(np.int64)))
+    assert np.array_equal(ids2.numpy(), sel) and none is None and sh._ids_cap >= 2
+    empty, mx0 = sh.allgather_ids(torch.zeros(0, dtype=torch.int64), extra=-1.0 - rank)
+    assert empty.numel() == 0 and mx0 == -1.0
+
     # reductions and broadcast
     assert sh.all_min(float(rank + 1)) == 1.0 and sh.all_max(float(rank + 1)) == float(world)
     assert sh.all_min_int((1 << 64) - 1 if rank == 0 else 12345) == 12345

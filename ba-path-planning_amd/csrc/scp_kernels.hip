@@ -576,9 +576,19 @@ __device__ inline void pair_row(const PairGeom<D>& g, const Pt<D>& Qi, const Pt<
 // the fully coalesced, 16-byte-per-lane streaming write (linearize) or read (violations) of the compact rows:
 // 8*(D+1) bytes per row.  PAIR_UNROLL independent steps per thread keep loads/stores and the fp64 chains of
 // several rows in flight; the selection / first-violation bookkeeping is behind a wave-uniform ballot.
+#ifdef SCP_PHASE_PROFILE
+// developer build (make prof): shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) every workgroup of the latest
+// pairwise kernel spent -> the clock the kernel actually ran at (MI355X_MICROARCH.md, in-kernel clock check)
+constexpr int SCP_PAIR_CLK_WGS = 4096;
+__device__ unsigned long long scp_pair_clk[2 * SCP_PAIR_CLK_WGS];
+#endif
+
 template <int D, int MODE, bool USE_LDS>
 __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
   constexpr int PAIR_UNROLL = PairUnroll<USE_LDS, MODE>::value;
+#ifdef SCP_PHASE_PROFILE
+  const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int N = a.N;
   const int k = blockIdx.y;
@@ -847,6 +857,15 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
       if (m > cur) atomic_max_double(&a.stats->max_violation, m);
     }
   }
+#ifdef SCP_PHASE_PROFILE
+  if (threadIdx.x == 0) {
+    const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg < (unsigned)SCP_PAIR_CLK_WGS) {
+      scp_pair_clk[2 * wg] = __builtin_amdgcn_s_memtime() - clk_c0;
+      scp_pair_clk[2 * wg + 1] = __builtin_amdgcn_s_memrealtime() - clk_t0;
+    }
+  }
+#endif
 }
 
 // scratch for the time-major slices (grown on demand, owned by the ctx)
@@ -930,6 +949,14 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
   ctx->pair_timed = true;
   return SCP_OK;
 }
+
+#ifdef SCP_PHASE_PROFILE
+// developer hook of the profiling build only (not declared in include/scp_hip.h): the per-workgroup stamps above
+extern "C" int scp_debug_pair_clocks(unsigned long long* out, int n) {
+  if (n > 2 * SCP_PAIR_CLK_WGS) n = 2 * SCP_PAIR_CLK_WGS;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(scp_pair_clk), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // Device time of the most recent pairwise kernel alone (HIP events on the ctx stream around that one launch).
 extern "C" int scp_ctx_last_pair_ms(scp_ctx* ctx, float* ms) {

@@ -858,6 +858,7 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
   qp->persist_skip_solve = false;
   qp->persist_gave_up_total = 0;
   qp->persist_variant = 0;
+  qp->steps_since_reset = 0;
   memset(qp->lim, 0, sizeof(qp->lim));
   qp->persist_fault = 0;
   qp->persist_cap_nW = -1;
@@ -968,6 +969,7 @@ extern "C" int scp_qp_reset(scp_qp* qp, const double* x0) {
   qp->nW = 0;
   qp->persist_cap_nW = -1;
   qp->persist_off = false;  // every new QP tries the persistent path again
+  qp->steps_since_reset = 0;
   qp->rho = qp->st.rho;
   qp->cg1_ready = false;
   qp->csr_valid = false;
@@ -975,6 +977,15 @@ extern "C" int scp_qp_reset(scp_qp* qp, const double* x0) {
   QP_CHECK(build_kkt(qp));
   qp->reset_done = true;
   return SCP_OK;
+}
+
+extern "C" int scp_qp_set_rho(scp_qp* qp, double rho) {
+  if (!qp) return SCP_ERR_INVALID;
+  if (!qp->reset_done) return scp_fail(qp->ctx, SCP_ERR_STATE, "qp_set_rho: call scp_qp_reset first");
+  SCP_REQUIRE(qp->ctx, rho >= 1e-6 && rho <= 1e6, "qp_set_rho: rho out of range");
+  qp->rho = rho;
+  qp->cg1_ready = false;  // the carried row values depend on rho
+  return build_kkt(qp);
 }
 
 // eta_stride == 0: gathered rows (the public entry point); > 0: eta / l are the arrays of the pairwise pass over the pair
@@ -1081,6 +1092,7 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
         info->rho_switches_in_kernel += qp->persist_rho_switches;
         pipes |= 1 << (qp->persist_variant ? SCP_PIPE_PERSIST16 : SCP_PIPE_PERSIST);
         cg_total += it_done - it;
+        qp->steps_since_reset += it_done - it;
         it = it_done;
         qp->qx_fresh = true;  // the kernel's last check left F x and S0 x exact
         persist_done = true;
@@ -1098,7 +1110,10 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
       n_it = st.check_termination - it % st.check_termination;
       if (it + n_it > st.max_iter) n_it = st.max_iter - it;
     }
-    if (!persist_done) it += n_it;
+    if (!persist_done) {
+      it += n_it;
+      qp->steps_since_reset += n_it;
+    }
     const bool will_check = persist_done || it % st.check_termination == 0 || it >= st.max_iter;
     const bool with_dy = will_check && st.eps_prim_inf > 0.0;
     if (!persist_done) {
@@ -1203,6 +1218,7 @@ extern "C" int scp_qp_clone_state(scp_qp* dst, const scp_qp* src) {
   }
 #undef CP
   memcpy(dst->lim, src->lim, sizeof(dst->lim));
+  dst->steps_since_reset = src->steps_since_reset;
   dst->nW = src->nW;
   dst->persist_cap_nW = -1;
   dst->rho = src->rho;

@@ -719,7 +719,11 @@ static int persist_variant_for(const scp_qp* qp) {
 bool scp_qp_persist_eligible(const scp_qp* qp) {
   if (!qp->st.persistent || qp->st.cg_iters != 1 || qp->st.use_mfma != 1) return false;
   if (qp->K > 64 || qp->nW <= 0 || qp->persist_off) return false;
-  return persist_variant_for(qp) >= 0;
+  const int variant = persist_variant_for(qp);
+  // the lean kernel's one-double-per-row state presumes z = Pi(z + y / rho), which any ADMM update establishes and
+  // scp_qp_reset (z = A x0, unprojected) does not: the first step of a QP is left to the three-launch pipeline
+  if (variant == 1 && qp->steps_since_reset == 0) return false;
+  return variant >= 0;
 }
 
 // Run ADMM iterations from iteration count `it0` of the current solve in ONE launch, termination checks included, until

@@ -5,10 +5,14 @@
 // /root/reference/src/path_planning/solvers/scp.py:441-445 like its sibling; same algorithm, same exchanges, same exit
 // protocol (scp_qp_persist_device.h) -- what changes is the register diet that four waves per SIMD (128 registers each)
 // demand:
-//   * carried per lane (= time step of the wave's agent): z, y of the 4 row types, x and its first / second prefix sums
-//     c1 = cumsum(x), c2 = cumsum(c1) (exclusive) -- F x and S0 x are re-derived from (x, c1, c2) where the 8-agent kernel
-//     carries the F x slab (16 registers) and S0 x; F (x + a p) likewise comes from (c1 + a cumsum p, c2 + a cumsum^2 p), so
-//     F p is never formed.  Same quantities, sums associated differently (rounding level);
+//   * ONE double per fixed row instead of two: v = z~ + y / rho, the point the projection is applied to.  ADMM's update
+//     z' = Pi(v'), y' = rho (v' - Pi(v')) with v' = alpha F x~ + (1 - alpha) z + y / rho keeps z = Pi(v), y = rho (v - Pi(v)) as an
+//     invariant, so v' = v + alpha (F x~ - Pi(v)) and z, y are two clamps away wherever they are needed ("one
+//     state double per row").  The invariant holds after any ADMM update but not after scp_qp_reset (z = A x0 unprojected):
+//     the host runs the first step of a QP on the three-launch pipeline (scp_qp_solve).  Rounding-level differences only;
+//   * x and its first / second prefix sums c1 = cumsum(x), c2 = cumsum(c1) (exclusive) are carried, and F x, S0 x re-derived
+//     from them where the 8-agent kernel carries the F x slab (16 registers) and S0 x; F (x + a p) likewise comes from
+//     (c1 + a cumsum p, c2 + a cumsum^2 p), so F p is never formed.  Same quantities, sums associated differently;
 //   * the jerk / acceleration limits are scalars (scp.py:188-195: the same for every row), only the velocity / position
 //     bounds are per row;
 //   * H_f^{-1} (packed MFMA operands, 26 KB at K = 50) lives in LDS and is streamed into the matrix cores, not held in 32
@@ -54,6 +58,8 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
   constexpr int D = 2;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ double red[NCHK][APB16];
+  __shared__ double cert_s[3][APB16];  // per wave: |dy|, support value, |A^T dy| of the batch's last step (fixed rows)
+  __shared__ double chk_s[NCHK];       // the nine results of the latest check (read again only at the exit)
   __shared__ int fail_s;
   const int K = A.K, N = A.N;
   const int64_t C = A.C;
@@ -132,19 +138,19 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
 
   // ---- column state: lane k of the agent's wave holds the rows of time step k --------------------------------------
   // row types t = 0 jerk (k < K - 1), 1 acc, 2 vel, 3 pos;  slab row of (t, k): t = 0: k, else t K - 1 + k
-  double z[D][4], y[D][4], lo[D][2], hi[D][2], x[D], c1[D], c2[D];
+  double v[D][4], lo[D][2], hi[D][2], x[D], c1[D], c2[D];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const bool rok = t == 0 ? jok : live;
     const int row = t == 0 ? k : t * K - 1 + k;
+    const double rr = (t >= 2 && lastk) ? rho * A.rho_eq : rho;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      z[d][t] = y[d][t] = 0.0;
+      v[d][t] = 0.0;
       if (t >= 2) lo[d][t - 2] = hi[d][t - 2] = 0.0;
       if (rok) {
         const int64_t g = (int64_t)row * C + (int64_t)agent * D + d;
-        z[d][t] = A.zf[g];
-        y[d][t] = A.yf[g];
+        v[d][t] = A.zf[g] + A.yf[g] / rr;
         if (t >= 2) { lo[d][t - 2] = A.lf[g]; hi[d][t - 2] = A.uf[g]; }
       }
     }
@@ -171,9 +177,8 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
   int it_done = A.it0;      // ADMM iterations of this solve completed so far
   unsigned steps = 0;       // steps run by this launch
   unsigned exit_code = 0;
-  double chk[NCHK];
   const bool with_dy = A.eps_prim_inf > 0.0;
-  double m_ndy = 0.0, m_supp = 0.0, m_natdy = 0.0;  // delta-y of the batch's last step, reduced on the spot
+  if (threadIdx.x < 3 * APB16) (&cert_s[0][0])[threadIdx.x] = 0.0;
   for (;;) {  // one batch of steps up to the next termination check, then the check and the decision to go on
   int nit = A.check_every - it_done % A.check_every;
   if (it_done + nit > A.max_iter) nit = A.max_iter - it_done;
@@ -183,8 +188,8 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
     u64* gpart = A.gpart + (size_t)(tag & 1u) * nblk * 4;
     const double rv = lastk ? rho * A.rho_eq : rho;   // rho of this lane's velocity / position rows
     // ---- r = -2 x + F^T W' + S0^T G: reverse cumulative sums as suffix scans over the lanes ------------------------
-    double r[D];
     {
+      double r[D];
       double g[D];
 #pragma unroll
       for (int d = 0; d < D; ++d) g[d] = 0.0;
@@ -195,11 +200,14 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
       }
 #pragma unroll
       for (int d = 0; d < D; ++d) {
+        // W' = rho (z - F x) - y with z = Pi(v), y = rho (v - Pi(v))
         const double xn = lane_above(x[d]);
-        const double wj = jok ? rho * (z[d][0] - (xn - x[d]) * ih) - y[d][0] : 0.0;
-        const double wa = rho * (z[d][1] - x[d]) - y[d][1];
-        const double wv = rv * (z[d][2] - h * c1[d]) - y[d][2];
-        const double wp = rv * (z[d][3] - hh * (c2[d] + 0.5 * c1[d])) - y[d][3];
+        const double cj = fmin(fmax(v[d][0], jlo), jhi), ca = fmin(fmax(v[d][1], alo), ahi);
+        const double cv = fmin(fmax(v[d][2], lo[d][0]), hi[d][0]), cp = fmin(fmax(v[d][3], lo[d][1]), hi[d][1]);
+        const double wj = jok ? rho * ((cj - (xn - x[d]) * ih) - (v[d][0] - cj)) : 0.0;
+        const double wa = rho * ((ca - x[d]) - (v[d][1] - ca));
+        const double wv = rv * ((cv - h * c1[d]) - (v[d][2] - cv));
+        const double wp = rv * ((cp - hh * (c2[d] + 0.5 * c1[d])) - (v[d][3] - cp));
         const double u1 = h * wv + 0.5 * hh * (wp - g[d]);
         const double u2 = wp + g[d];
         const double d1 = wave_incl_rsum(u1);
@@ -208,6 +216,7 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
         const double wjm = lane_below(wj);                  // w_j[k - 1]
         r[d] = (((wjm - wj) * ih + wa) + (d1 + 0.5 * hh * g[d]) + hh * d2) - 2.0 * x[d];
         if (live) my_rt[d * RSK] = r[d];
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         p[d] = live ? my_pt[d * RSK] : 0.0;
-        rz += r[d] * p[d];  // (r = 0 beyond the horizon is not guaranteed, p is)
+        rz += (live ? my_rt[d * RSK] : 0.0) * p[d];  // r of this lane, re-read from its tile
         const double cs1 = wave_incl_sum(p[d]);
         const double cs2 = lane_below(wave_incl_sum(cs1));
         const double qp = hh * (cs2 - 0.5 * lane_below(cs1));
@@ -368,55 +377,31 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
       }
     }
     const bool cert = last && with_dy;
-    if (cert) {
-      __syncthreads();  // (uniform: every lane of the grid takes it)
-      m_ndy = m_supp = m_natdy = 0.0;
-    }
+    if (cert) __syncthreads();  // (uniform: every lane of the grid takes it) the rows' delta-y are parked
+    double m_ndy = 0.0, m_supp = 0.0, m_natdy = 0.0;  // delta-y of this step, reduced on the spot (certificate)
     // ---- fixed rows: z~ = F (x + a p) from the combined prefix sums, relaxation, projection, duals -----------------------
     {
-      const double irho = 1.0 / rho, irv = lastk ? 1.0 / (rho * A.rho_eq) : irho;
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const double xt = fma(a, p[d], x[d]);
         const double t1 = fma(a, s1p[d], c1[d]), t2 = fma(a, s2p[d], c2[d]);
         const double xtn = lane_above(xt);
-        double dyj = 0.0, dya, dyv, dyp;
-        if (jok) {  // jerk
-          const double zh = alpha * ((xtn - xt) * ih) + (1.0 - alpha) * z[d][0];
-          const double yo = y[d][0];
-          const double zn = fmin(fmax(zh + yo * irho, jlo), jhi);
-          const double yn = yo + rho * (zh - zn);
-          dyj = yn - yo; y[d][0] = yn; z[d][0] = zn;
-        }
-        {  // acceleration
-          const double zh = alpha * xt + (1.0 - alpha) * z[d][1];
-          const double yo = y[d][1];
-          const double zn = fmin(fmax(zh + yo * irho, alo), ahi);
-          const double yn = yo + rho * (zh - zn);
-          dya = yn - yo; y[d][1] = yn; z[d][1] = zn;
-        }
-        {  // velocity (state k + 1)
-          const double zh = alpha * (h * t1) + (1.0 - alpha) * z[d][2];
-          const double yo = y[d][2];
-          const double zn = fmin(fmax(zh + yo * irv, lo[d][0]), hi[d][0]);
-          const double yn = yo + rv * (zh - zn);
-          dyv = yn - yo; y[d][2] = yn; z[d][2] = zn;
-        }
-        {  // position (state k + 1)
-          const double zh = alpha * (hh * (t2 + 0.5 * t1)) + (1.0 - alpha) * z[d][3];
-          const double yo = y[d][3];
-          const double zn = fmin(fmax(zh + yo * irv, lo[d][1]), hi[d][1]);
-          const double yn = yo + rv * (zh - zn);
-          dyp = yn - yo; y[d][3] = yn; z[d][3] = zn;
-        }
-        x[d] = fma(aa, p[d], x[d]);
-        c1[d] = fma(aa, s1p[d], c1[d]);
-        c2[d] = fma(aa, s2p[d], c2[d]);
+        // v' = v + alpha (F x~ - Pi(v)); the new z, y are Pi(v'), rho (v' - Pi(v'))
+        const double cj = fmin(fmax(v[d][0], jlo), jhi), ca = fmin(fmax(v[d][1], alo), ahi);
+        const double cv = fmin(fmax(v[d][2], lo[d][0]), hi[d][0]), cp = fmin(fmax(v[d][3], lo[d][1]), hi[d][1]);
+        const double nj = jok ? fma(alpha, (xtn - xt) * ih - cj, v[d][0]) : v[d][0];
+        const double na = fma(alpha, xt - ca, v[d][1]);
+        const double nv = fma(alpha, h * t1 - cv, v[d][2]);
+        const double np = fma(alpha, hh * (t2 + 0.5 * t1) - cp, v[d][3]);
         if (cert) {
-          // OSQP's certificate on delta-y of this step: |dy|, the support value u.dy+ + l.dy-, and A^T dy by the r chain
-          if (!live) dya = dyv = dyp = 0.0;
+          // OSQP's certificate on delta-y = rho [(v' - Pi(v')) - (v - Pi(v))] of this step: |dy|, the support value
+          // u.dy+ + l.dy-, and A^T dy by the r chain
+          const double dyj = rho * ((nj - fmin(fmax(nj, jlo), jhi)) - (v[d][0] - cj));
+          const double dya = rho * ((na - fmin(fmax(na, alo), ahi)) - (v[d][1] - ca));
+          const double dyv = rv * ((nv - fmin(fmax(nv, lo[d][0]), hi[d][0])) - (v[d][2] - cv));
+          const double dyp = rv * ((np - fmin(fmax(np, lo[d][1]), hi[d][1])) - (v[d][3] - cp));
           m_ndy = fmax(m_ndy, fmax(fmax(fabs(dyj), fabs(dya)), fmax(fabs(dyv), fabs(dyp))));
-          m_supp += (jhi * fmax(dyj, 0.0) + jlo * fmin(dyj, 0.0)) + (live ? ahi * fmax(dya, 0.0) + alo * fmin(dya, 0.0) : 0.0) +
+          m_supp += (jhi * fmax(dyj, 0.0) + jlo * fmin(dyj, 0.0)) + (ahi * fmax(dya, 0.0) + alo * fmin(dya, 0.0)) +
                     (hi[d][0] * fmax(dyv, 0.0) + lo[d][0] * fmin(dyv, 0.0)) + (hi[d][1] * fmax(dyp, 0.0) + lo[d][1] * fmin(dyp, 0.0));
           double gd = 0.0;
           for (int e = c0; e < c1e; ++e) gd += e_c[(size_t)e * D + d] * e_pp[(size_t)e * D];
@@ -429,7 +414,18 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
           const double at = ((vjm - dyj) * ih + dya) + (d1 + 0.5 * hh * gd) + hh * d2;
           if (live) m_natdy = fmax(m_natdy, fabs(at));
         }
+        v[d][0] = nj; v[d][1] = na; v[d][2] = nv; v[d][3] = np;
+        x[d] = fma(aa, p[d], x[d]);
+        c1[d] = fma(aa, s1p[d], c1[d]);
+        c2[d] = fma(aa, s2p[d], c2[d]);
+        __builtin_amdgcn_sched_barrier(0);  // one column at a time: interleaving both doubles the temporaries
       }
+    }
+    if (cert) {
+      m_ndy = wave_max_nn(m_ndy);
+      m_supp = wave_incl_sum(m_supp);
+      m_natdy = wave_max_nn(m_natdy);
+      if (lane == 63) { cert_s[0][wave] = m_ndy; cert_s[1][wave] = m_supp; cert_s[2][wave] = m_natdy; }
     }
     __syncthreads();
   }
@@ -440,11 +436,9 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
   {
     const unsigned ctag = 0x80000000u | (A.epoch0 + steps);
     const double rv = lastk ? rho * A.rho_eq : rho;
-    (void)rv;
     double m[NCHK];
 #pragma unroll
     for (int j = 0; j < NCHK; ++j) m[j] = 0.0;
-    m[CK_NDY] = m_ndy; m[CK_SUPP] = m_supp; m[CK_NATDY] = m_natdy;
     {
       double gy[D];
 #pragma unroll
@@ -467,16 +461,19 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
         }
         const double xn = lane_above(x[d]);
         const double f[4] = {jok ? (xn - x[d]) * ih : 0.0, x[d], h * c1[d], hh * (c2[d] + 0.5 * c1[d])};
+        const double zc[4] = {fmin(fmax(v[d][0], jlo), jhi), fmin(fmax(v[d][1], alo), ahi),
+                              fmin(fmax(v[d][2], lo[d][0]), hi[d][0]), fmin(fmax(v[d][3], lo[d][1]), hi[d][1])};  // z = Pi(v)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           if (t == 0 ? jok : live) {
-            m[CK_RP] = fmax(m[CK_RP], fabs(f[t] - z[d][t]));
+            m[CK_RP] = fmax(m[CK_RP], fabs(f[t] - zc[t]));
             m[CK_NAX] = fmax(m[CK_NAX], fabs(f[t]));
-            m[CK_NZ] = fmax(m[CK_NZ], fabs(z[d][t]));
+            m[CK_NZ] = fmax(m[CK_NZ], fabs(zc[t]));
           }
         }
-        // A^T y: the r chain with W' -> y
-        const double vj = y[d][0], va = y[d][1], vv = y[d][2], vp = y[d][3];
+        // A^T y: the r chain with W' -> y = rho (v - Pi(v))
+        const double vj = jok ? rho * (v[d][0] - zc[0]) : 0.0, va = rho * (v[d][1] - zc[1]);
+        const double vv = rv * (v[d][2] - zc[2]), vp = rv * (v[d][3] - zc[3]);
         const double g = gy[d];
         const double u1 = h * vv + 0.5 * hh * (vp - g);
         const double u2 = vp + g;
@@ -491,6 +488,7 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
           m[CK_NPX] = fmax(m[CK_NPX], fabs(px));
           m[CK_NATY] = fmax(m[CK_NATY], fabs(at));
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
@@ -541,8 +539,13 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
     }
 #pragma unroll
     for (int j = 0; j < NCHK; ++j) {
-      const double v = j == CK_SUPP ? wave_incl_sum(m[j]) : wave_max_nn(m[j]);
-      if (lane == 63) red[j][wave] = v;
+      double v = j == CK_SUPP ? wave_incl_sum(m[j]) : wave_max_nn(m[j]);
+      if (lane == 63) {  // + the fixed rows' share of the certificate, reduced when the last step produced it
+        if (j == CK_NDY) v = fmax(v, cert_s[0][wave]);
+        if (j == CK_SUPP) v += cert_s[1][wave];
+        if (j == CK_NATDY) v = fmax(v, cert_s[2][wave]);
+        red[j][wave] = v;
+      }
     }
     __syncthreads();
     if (fail_s) { ok = false; break; }
@@ -577,11 +580,16 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
     }
     __syncthreads();
     if (fail_s) { ok = false; break; }
+    double chk[NCHK];
 #pragma unroll
     for (int j = 0; j < NCHK; ++j) {  // the same reduction order in every wave of every workgroup: identical decisions
       double v = 0.0;
       for (int b = lane; b < nblk; b += 64) v = j == CK_SUPP ? v + gck[b * NCHK + j] : fmax(v, gck[b * NCHK + j]);
       chk[j] = read_lane(j == CK_SUPP ? wave_incl_sum(v) : wave_max_nn(v), 63);
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int j = 0; j < NCHK; ++j) chk_s[j] = chk[j];
     }
     __syncthreads();  // gck may share its LDS with the r / p tiles of the next step
     if (L.gchk == L.rt) {  // ... which must be zero in the columns beyond the block again
@@ -607,6 +615,16 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
         const double nrs = A.tab[slot].rho;
         if (nrs > rho * A.rho_tol || nrs < rho / A.rho_tol) {
           // ---- switch rho in place (what the host does between two launches: build_kkt hit + rows_value_kernel) -------------
+          {  // y = rho (v - Pi(v)) must survive the switch: v <- Pi(v) + (v - Pi(v)) rho_old / rho_new
+            const double ratio = rho / nrs;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+              const double zc[4] = {fmin(fmax(v[d][0], jlo), jhi), fmin(fmax(v[d][1], alo), ahi),
+                                    fmin(fmax(v[d][2], lo[d][0]), hi[d][0]), fmin(fmax(v[d][3], lo[d][1]), hi[d][1])};
+#pragma unroll
+              for (int t = 0; t < 4; ++t) v[d][t] = fma(v[d][t] - zc[t], ratio, zc[t]);
+            }
+          }
           rho = nrs;
           rho_c = rho * A.rho_col_scale;
           for (int i = threadIdx.x; i < tK * nks * 64; i += NT16) Ml[i] = A.tab[slot].pMinv[i];
@@ -641,13 +659,15 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
     const double xn = lane_above(x[d]);
     const double c1b = lane_below(c1[d]);
     const double f[4] = {(xn - x[d]) * ih, x[d], h * c1[d], hh * (c2[d] + 0.5 * c1[d])};
+    const double zc[4] = {fmin(fmax(v[d][0], jlo), jhi), fmin(fmax(v[d][1], alo), ahi),
+                          fmin(fmax(v[d][2], lo[d][0]), hi[d][0]), fmin(fmax(v[d][3], lo[d][1]), hi[d][1])};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (t == 0 ? jok : live) {
         const int row = t == 0 ? k : t * K - 1 + k;
         const int64_t g = (int64_t)row * C + (int64_t)agent * D + d;
-        A.zf[g] = z[d][t];
-        A.yf[g] = y[d][t];
+        A.zf[g] = zc[t];
+        A.yf[g] = ((t >= 2 && lastk) ? rho * A.rho_eq : rho) * (v[d][t] - zc[t]);
         A.fx[g] = f[t];
       }
     }
@@ -670,7 +690,7 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
     const int slot[NCHK] = {SL_RP, SL_NAX, SL_NZ, SL_RD, SL_NPX, SL_NATY, SL_NDY, SL_SUPP, SL_NATDY};
 #pragma unroll
     for (int j = 0; j < NCHK; ++j)
-      __hip_atomic_store((u64*)(A.host_scal + slot[j]), (u64)__double_as_longlong(chk[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store((u64*)(A.host_scal + slot[j]), (u64)__double_as_longlong(chk_s[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(A.host_status + 1, (unsigned)it_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(A.host_status + 2, n_rho, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store((u64*)A.host_rho, (u64)__double_as_longlong(rho), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

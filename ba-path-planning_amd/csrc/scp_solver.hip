@@ -58,6 +58,7 @@ struct scp_solver {
   // trajectories [N][K][D]
   double *acc, *x, *pos_a, *pos_b, *vel;
   double* pair_pts;  // pinned, 2 D doubles: the two positions of the first violation
+  double rho_start;  // > 0: the joint QP of the next step starts at this rho (options.carry_rho), else at settings.rho
   struct StepState* step;  // the SCP iteration in flight (phases of solve_joint_qp / of the sharded entry points)
 };
 
@@ -222,6 +223,7 @@ int step_qp_round(scp_solver* s, StepState& t, const int64_t* rows, int64_t n, s
   if (first) {
     SV_CHECK(scp_qp_update_settings(s->qp, &s->st));
     SV_CHECK(scp_qp_reset(s->qp, t.acc_in));
+    if (s->rho_start > 0.0) SV_CHECK(scp_qp_set_rho(s->qp, s->rho_start));
   }
   SV_CHECK(add_rows_growing(s, t, rows, n, !first));
   t.nW += n;
@@ -329,7 +331,7 @@ extern "C" void scp_solve_default_options(scp_solve_options* o) {
   o->polish_eps = 1e-8;
   o->convergence_tolerance = 1.5e-2;  // scp.py:52
   o->row_free = 1;
-  o->reserved = 0;
+  o->carry_rho = 0;
 }
 
 extern "C" void scp_solver_destroy(scp_solver* s) {
@@ -459,10 +461,12 @@ extern "C" int scp_solver_solve(scp_solver* s, const double* limits, const doubl
   int iteration = 0;
   bool converged = false;
   double* acc = s->acc;
+  s->rho_start = 0.0;
   while (iteration < o->max_iterations && !converged && !is_feasible) {
     const double t_it = now_s();
     scp_qp_record* rec = &records[res->n_records];
     SV_CHECK(solve_joint_qp(s, acc, limits, space, p0, v0, pf, vf, o, 0.0, rec));
+    if (o->carry_rho) s->rho_start = rec->rho;  // the next linearisation's QP starts where this one ended
     double rel[3];
     SV_CHECK(scp_rel_step(ctx, (int64_t)N * K * D, s->x, acc, rel));  // scp.py:157-159 (no zero guard)
     rec->rel_step = rel[2];
@@ -479,6 +483,7 @@ extern "C" int scp_solver_solve(scp_solver* s, const double* limits, const doubl
       is_feasible = s->h_stats->first_violation == UINT64_MAX;
     }
   }
+  s->rho_start = 0.0;  // (the polish QP and later solves start at settings.rho)
   res->n_iterations = iteration;
   res->converged = converged ? 1 : 0;
   res->feasible_at_exit = is_feasible ? 1 : 0;
@@ -510,6 +515,7 @@ extern "C" int scp_solver_step(scp_solver* s, const double* limits, const double
   const int N = s->N, K = s->K, D = s->D;
   const size_t nbytes = (size_t)N * K * D * sizeof(double);
   const double t0 = now_s();
+  s->rho_start = 0.0;
   SV_CHECK(scp_qp_set_problem(s->qp, limits, space, p0, v0, pf, vf));
   SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, acc_in, p0, v0, s->pos_a, nullptr));
   SV_CHECK(solve_joint_qp(s, acc_in, limits, space, p0, v0, pf, vf, o, 0.0, rec));
@@ -547,6 +553,7 @@ extern "C" int scp_solver_shard_begin(scp_solver* s, const double* limits, const
   const int N = s->N, K = s->K, D = s->D;
   StepState& t = *s->step;
   step_restore(s, t);
+  s->rho_start = 0.0;
   double lim[6], spc[6];
   memcpy(lim, limits, sizeof(lim));
   memcpy(spc, space, 2 * D * sizeof(double));

@@ -58,7 +58,7 @@ class SolveOptions(C.Structure):
         ("max_iterations", C.c_int32), ("max_rounds", C.c_int32), ("max_iter0", C.c_int32), ("max_iter", C.c_int32),
         ("refresh_feasibility", C.c_int32), ("polish", C.c_int32), ("working_set_margin", C.c_double),
         ("feasibility_tol", C.c_double), ("polish_eps", C.c_double), ("convergence_tolerance", C.c_double),
-        ("row_free", C.c_int32), ("reserved", C.c_int32),
+        ("row_free", C.c_int32), ("carry_rho", C.c_int32),
     ]
 
 
@@ -125,7 +125,7 @@ EXPORTS = [
     "scp_kinematics", "scp_fixed_bounds", "scp_linearize_pairs", "scp_select_pairs", "scp_check_avoidance", "scp_qp_add_rows_at",
     "scp_collision_violations", "scp_collision_violations_at", "scp_gather_rows", "scp_rel_step", "scp_qp_default_settings",
     "scp_qp_workspace_bytes", "scp_qp_create", "scp_qp_destroy", "scp_qp_update_settings", "scp_qp_set_problem",
-    "scp_qp_reset", "scp_qp_add_rows", "scp_qp_solve", "scp_qp_clone_state", "scp_qp_get_solution",
+    "scp_qp_reset", "scp_qp_set_rho", "scp_qp_add_rows", "scp_qp_solve", "scp_qp_clone_state", "scp_qp_get_solution",
     "scp_qp_get_duals", "scp_gemm_f64", "scp_qp_peek", "scp_qp_debug_set",
     "scp_solve_default_options", "scp_solver_create", "scp_solver_destroy", "scp_solver_update_settings", "scp_solver_solve",
     "scp_solver_step", "scp_solver_shard_begin", "scp_solver_shard_rows", "scp_solver_shard_qp", "scp_solver_shard_violations",
@@ -186,6 +186,7 @@ def load_library():
     lib.scp_qp_update_settings.argtypes = [vp, C.POINTER(QpSettings)]
     lib.scp_qp_set_problem.argtypes = [vp, pd, pd, vp, vp, vp, vp]
     lib.scp_qp_reset.argtypes = [vp, vp]
+    lib.scp_qp_set_rho.argtypes = [vp, f64]
     lib.scp_qp_add_rows.argtypes = [vp, i64, vp, vp, vp]
     lib.scp_qp_add_rows_at.argtypes = [vp, i64, vp, vp, vp, vp, f64]
     lib.scp_qp_solve.argtypes = [vp, C.POINTER(QpInfo)]
@@ -490,6 +491,9 @@ class QP:
     def reset(self, x0=None):
         self.ctx.check(self.ctx.lib.scp_qp_reset(self.h_qp, x0.data_ptr() if x0 is not None else None))
         self.n_rows = 0
+
+    def set_rho(self, rho):
+        self.ctx.check(self.ctx.lib.scp_qp_set_rho(self.h_qp, float(rho)))
 
     def add_rows(self, rows, w_eta, w_l):
         n = int(rows.numel())

@@ -21,6 +21,9 @@ class Shard:
         if self.world > 1 and not dist.is_initialized():
             raise RuntimeError("world_size > 1 needs an initialised torch.distributed process group")
         self.pairs = self.N * (self.N - 1) // 2
+        # host wall time spent inside the exchanges (staging copies of a gloo rehearsal included) and their count: what a
+        # multi-rank step adds to the single-rank one (bench.py reports it per step)
+        self.comm_seconds, self.comm_calls = 0.0, 0
 
     # ---- partitions ----------------------------------------------------------------------------
     def pair_range(self, rank=None):
@@ -37,6 +40,25 @@ class Shard:
         ("nccl") the collectives run on the device buffers directly."""
         return tensor.is_cuda and dist.get_backend(self.group) == "gloo"
 
+    def _timed(fn):  # noqa: N805  (decorator in the class body)
+        import functools
+        import time
+
+        @functools.wraps(fn)
+        def wrapper(self, *a, **kw):
+            if self.world == 1 or getattr(self, "_in_exchange", False):
+                return fn(self, *a, **kw)
+            self._in_exchange = True
+            t0 = time.perf_counter()
+            try:
+                return fn(self, *a, **kw)
+            finally:
+                self.comm_seconds += time.perf_counter() - t0
+                self.comm_calls += 1
+                self._in_exchange = False
+        return wrapper
+
+    @_timed
     def allgather_positions(self, local):
         """local: (n_local, K, D) trajectories of this rank's agents -> (N, K, D) on every rank."""
         if self.world == 1:
@@ -55,6 +77,7 @@ class Shard:
         dist.all_gather(parts, pad, group=self.group)
         return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
 
+    @_timed
     def allgather_rows(self, rows, w_eta, w_l):
         """Concatenate every rank's compact rows (ids (n,), eta (n, D), l (n,)) in rank order.
 
@@ -88,6 +111,7 @@ class Shard:
         all_ids, all_vals = all_ids[keep], all_vals[keep]
         return all_ids.contiguous(), all_vals[:, :D].contiguous(), all_vals[:, D].contiguous()
 
+    @_timed
     def allgather_ids(self, rows, extra=None):
         """Every rank's row ids (int64, any length) merged in ascending order -- the order a single rank would have found
         them in, so the replicated QP builds the same working set bit for bit on every world size -- plus, optionally, the
@@ -122,6 +146,7 @@ class Shard:
         mx = float(head[:, 1].contiguous().view(torch.float64).max().item())
         return (ids.to(dev) if staged else ids).contiguous(), (mx if extra is not None else None)
 
+    @_timed
     def broadcast(self, tensor, src=0):
         if self.world > 1:
             if self._host_staged(tensor):

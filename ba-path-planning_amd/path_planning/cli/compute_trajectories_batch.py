@@ -80,6 +80,8 @@ def run_single_trial(N, cfg, rng=None, seed=None, device=None, scenario=None, sa
                 device=device,
                 verbose=cfg.get("verbose", False),
                 polish=cfg.get("polish", False),
+                carry_rho=cfg.get("carry_rho", False),
+                qp_settings=cfg.get("qp_settings"),
             )
             if pool is not None:
                 pool[key] = solver
@@ -194,6 +196,12 @@ def build_parser():
     p.add_argument("--warmup", type=int, default=0,
                    help="untimed solves per worker (stream) before the clock starts: the first solve of a worker builds its "
                         "solver object and loads the kernels (~0.1 s); with it the scenarios/s line is the steady-state rate")
+    p.add_argument("--qp-persistent", type=int, choices=[0, 1, 2], default=None,
+                   help="scp_qp_settings.persistent: 1 = persistent ADMM kernel with 8 agents per workgroup (default), 2 = its "
+                        "lean 16-agent form (half the compute units per solve: more solves side by side), 0 = three launches "
+                        "per ADMM step")
+    p.add_argument("--carry-rho", action="store_true",
+                   help="every joint QP after the first starts at the rho the previous SCP iteration ended with")
     p.add_argument("--streams", type=int, default=1,
                    help="solve this many scenarios concurrently on one GPU, each on its own HIP stream (a solve of "
                         "~100 agents is latency bound and leaves the GPU mostly idle)")
@@ -214,6 +222,9 @@ def main(argv=None):
             cfg[key] = val
     cfg["validate"] = bool(args.validate)
     cfg["polish"] = bool(args.polish)
+    cfg["carry_rho"] = bool(args.carry_rho)
+    if args.qp_persistent is not None:
+        cfg["qp_settings"] = {"persistent": int(args.qp_persistent)}
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

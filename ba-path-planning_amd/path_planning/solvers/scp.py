@@ -45,6 +45,7 @@ class SCP:
         polish_eps=1e-8,
         native=True,
         row_free=True,
+        carry_rho=False,
         qp_row_capacity=None,
         verbose=True,
         rank=0,
@@ -98,6 +99,10 @@ class SCP:
         # for the selected rows only (scp_qp_add_rows_at); False: scp_linearize_pairs writes every row (what
         # _add_collision_constraints returns, and what the Python-driven loop does).  Same working rows, same bits.
         self.row_free = bool(row_free)
+        # opt-in: the joint QP of SCP iteration n + 1 starts at the rho iteration n ended with instead of OSQP's 0.1 (the
+        # reference builds a new osqp.OSQP() per iteration, scp.py:441): saves the adaptive-rho transient of every later QP
+        self.carry_rho = bool(carry_rho)
+        self._rho_start = 0.0
         self._native = None
         self._qp_row_capacity = qp_row_capacity  # initial working-set capacity (grows on demand)
         self._qp_overrides = dict(qp_settings or {})
@@ -227,6 +232,7 @@ class SCP:
 
         iteration = 0
         converged = False
+        self._rho_start = 0.0
         self.last_info = {"iterations": [], "qp0": dict(self._last_qp_info)}
         # `is_feasible` is evaluated once and never refreshed inside the loop (scp.py:144, :152)
         while iteration < max_iterations and not converged and not is_feasible:
@@ -248,6 +254,8 @@ class SCP:
             self._print(rel_step_norm)
             self.last_info["iterations"].append(dict(self._last_qp_info, rel_step=rel_step_norm,
                                                      time_sec=time.perf_counter() - t_it))
+            if self.carry_rho:
+                self._rho_start = float(self._last_qp_info["rho"])
             if rel_step_norm <= self.convergence_tolerance:
                 converged = True
                 self._print(f"Converged after {iteration+1} iterations.")
@@ -261,6 +269,7 @@ class SCP:
                 is_feasible = self._fast_check_avoidance_constraints(pos_now)
                 self.verbose = verbose
 
+        self._rho_start = 0.0
         if self.polish:
             # opt-in (not in the reference): one more joint QP, linearised at the final trajectories and solved to
             # polish_eps instead of OSQP's 1e-3.  Every linearised row then holds to ~polish_eps, and a satisfied row
@@ -296,7 +305,8 @@ class SCP:
             max_iter0=int(self._qp_overrides.get("max_iter0", self._qp_overrides.get("max_iter", 4000))),
             max_iter=int(self._qp_overrides.get("max_iter", 10000)), refresh_feasibility=int(self.refresh_feasibility),
             polish=int(self.polish), working_set_margin=self.working_set_margin, feasibility_tol=self.feasibility_tol,
-            polish_eps=self.polish_eps, convergence_tolerance=self.convergence_tolerance, row_free=int(self.row_free))
+            polish_eps=self.polish_eps, convergence_tolerance=self.convergence_tolerance, row_free=int(self.row_free),
+            carry_rho=int(self.carry_rho))
 
     def scp_iteration(self, accelerations):
         """ONE pass of the SCP loop body (scp.py:152-166) in one library call (scp_solver_step): linearise around
@@ -545,6 +555,8 @@ class SCP:
         rows, w_eta, w_l = self.shard.allgather_rows(rows, w_eta, w_l)
 
         qp.reset(acc)
+        if self._rho_start > 0.0:
+            qp.set_rho(self._rho_start)
         try:
             qp.add_rows(rows, w_eta, w_l)
         except _hip.HipError as e:
@@ -552,6 +564,8 @@ class SCP:
                 raise
             qp = self._grow_qp(int(rows.numel()))
             qp.reset(acc)
+            if self._rho_start > 0.0:
+                qp.set_rho(self._rho_start)
             qp.add_rows(rows, w_eta, w_l)
 
         used = 0

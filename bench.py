@@ -148,6 +148,7 @@ def main():
         step()
     lin_ms, viol_ms, infos = [], [], []
     barrier()
+    comm0 = (solver.shard.comm_seconds, solver.shard.comm_calls)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         _, rel, lms, vms = step()
@@ -156,6 +157,7 @@ def main():
         infos.append(dict(solver._last_qp_info, rel_step=rel))
     barrier()
     dt = time.perf_counter() - t0
+    comm = ((solver.shard.comm_seconds - comm0[0]) / args.steps * 1e3, (solver.shard.comm_calls - comm0[1]) / args.steps)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -259,6 +261,11 @@ def main():
         },
     }
     out["row_free_step"] = row_free
+    if world > 1:
+        out["exchange"] = {"ms_per_step": comm[0], "collectives_per_step": comm[1], "backend": args.backend,
+                           "note": "host wall time of rank 0 inside the exchanges of one step (allgather of the per-shard "
+                                   "trajectories, of the selected / violated row ids per constraint-generation round); with "
+                                   "gloo this includes the device <-> host staging copies"}
     out["config"]["qp"]["pipeline"] = infos[-1].get("pipeline")
     out["config"]["qp"]["persist_gave_up"] = infos[-1].get("persist_gave_up")
     if traffic_note:

@@ -216,6 +216,9 @@ int scp_qp_set_problem(scp_qp* qp, const double* limits /*[host]*/, const double
 /* start a new QP: x = x0 ([N][K][D], NULL -> 0), z = A x, y = 0 (primal warm start only, scp.py:443),
  * empty working set, rho = settings.rho */
 int scp_qp_reset(scp_qp* qp, const double* x0);
+/* Start (or continue) from another step size than settings.rho -- e.g. the value the previous SCP iteration's QP ended with
+ * (scp_solve_options.carry_rho): the rho-dependent blocks are taken from the cache or rebuilt.  After scp_qp_reset. */
+int scp_qp_set_rho(scp_qp* qp, double rho);
 /* append working rows (global ids; eta AoS [n][D]; lower bounds); z = max(A x, l), y = 0 */
 int scp_qp_add_rows(scp_qp* qp, int64_t n, const int64_t* rows, const double* w_eta, const double* w_l);
 /* append working rows with eta / l recomputed from the linearisation point pos_prev ([N][K][D]) by the arithmetic of
@@ -254,7 +257,9 @@ typedef struct scp_solve_options {
   int32_t row_free;             /* 1: linearise with scp_select_pairs + scp_qp_add_rows_at (no eta / l planes are written
                                    or allocated); 0: scp_linearize_pairs writes all rows and the working rows are gathered
                                    from them.  Same working rows, same bits either way */
-  int32_t reserved;
+  int32_t carry_rho;            /* 0 (OSQP: every new solver object starts at settings.rho, scp.py:441); 1: the joint QP of SCP
+                                   iteration n + 1 starts at the rho iteration n ended with (its blocks are cached), which saves
+                                   the adaptive-rho transient: fewer ADMM steps, the same minimiser within eps */
 } scp_solve_options;
 
 #define SCP_MAX_ROUNDS_RECORDED 24

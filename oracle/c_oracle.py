@@ -98,7 +98,7 @@ def admm(prob, eta=None, l_col=None, dist=None, x0=None, st: qo.Settings | None 
     return x, d
 
 
-def scp_solve(prob, max_iterations=15, st: qo.Settings | None = None, max_iter0=4000):
+def scp_solve(prob, max_iterations=15, st: qo.Settings | None = None, max_iter0=4000, carry_rho=False):
     """generate_trajectories (scp.py:131-180) on the C oracle: the same loop as qp_oracle.scp_solve, for sizes the numpy
     oracle is too slow for (a 128-agent solve takes seconds here)."""
     import dataclasses
@@ -113,7 +113,8 @@ def scp_solve(prob, max_iterations=15, st: qo.Settings | None = None, max_iter0=
     it, converged = 0, False
     while it < max_iterations and not converged and not feasible:
         eta, l_col, dist = linearize_pairs(prob, pos)
-        xn, info = admm(prob, eta, l_col, dist, x0=x, st=st)
+        st_it = dataclasses.replace(st, rho=infos[-1]["rho"]) if (carry_rho and len(infos) > 1) else st
+        xn, info = admm(prob, eta, l_col, dist, x0=x, st=st_it)
         infos.append(info)
         rel = float(np.linalg.norm((xn - x).ravel()) / np.linalg.norm(x.ravel()))  # scp.py:157-159
         rels.append(rel)

@@ -458,8 +458,12 @@ def admm_structured(prob: so.Problem, eta=None, l_col=None, dist=None, x0=None, 
 # ---------------------------------------------------------------------------------------------
 # SCP outer loop (scp.py:131-180), oracle form
 # ---------------------------------------------------------------------------------------------
-def scp_solve(prob: so.Problem, max_iterations=15, st: Settings | None = None, force_iterations=None, log=None):
+def scp_solve(prob: so.Problem, max_iterations=15, st: Settings | None = None, force_iterations=None, log=None,
+              carry_rho=False):
     """generate_trajectories (scp.py:131-180) on top of admm_structured.
+
+    carry_rho (the solver's opt-in of the same name): the joint QP of iteration n + 1 starts at the rho iteration n ended
+    with instead of st.rho (the reference builds a new OSQP object per iteration, scp.py:441).
 
     `is_feasible` is evaluated once on QP#0's trajectory and never refreshed (scp.py:144, :152).
     force_iterations: run exactly that many loop bodies regardless of the flags (bench mode)."""
@@ -482,7 +486,8 @@ def scp_solve(prob: so.Problem, max_iterations=15, st: Settings | None = None, f
             break
         prev_pos, _ = so.kinematics(prob, x)
         eta, l_col, dist = so.linearize_pairs(prob, prev_pos)
-        x_new, _, info = admm_structured(prob, eta, l_col, dist, x0=x, st=st)
+        st_it = dataclasses.replace(st, rho=infos[-1]["rho"]) if (carry_rho and len(infos) > 1) else st
+        x_new, _, info = admm_structured(prob, eta, l_col, dist, x0=x, st=st_it)
         infos.append(info)
         rel = float(np.linalg.norm((x_new - x).ravel()) / np.linalg.norm(x.ravel()))  # scp.py:157-159
         rels.append(rel)

@@ -25,7 +25,8 @@ def same_records(a, b):
         assert a[k] == b[k] or (np.isnan(a[k]) and np.isnan(b[k])), (k, a[k], b[k])
 
 
-@pytest.mark.parametrize("case", ["ref10", "grid64", "grid3d27", "polish", "refresh", "tiny_capacity", "single_agent"])
+@pytest.mark.parametrize("case", ["ref10", "grid64", "grid3d27", "polish", "refresh", "tiny_capacity", "single_agent",
+                                  "carry_rho"])
 def test_native_loop_is_bit_identical(case):
     from path_planning.scenarios.position_generator import generate_grid_swap, generate_positions
 
@@ -34,9 +35,10 @@ def test_native_loop_is_bit_identical(case):
         p0, pf = generate_positions(10, 0.8, seed=7)
         n, space = 10, [0, 0, 20, 20]
         kw = {"polish": {"polish": True}, "refresh": {"refresh_feasibility": True}, "tiny_capacity": {"qp_row_capacity": 4}}.get(case, {})
-    elif case == "grid64":
+    elif case in ("grid64", "carry_rho"):
         n = 64
         p0, pf, space = generate_grid_swap(n, seed=64000)
+        kw = {"carry_rho": True} if case == "carry_rho" else {}
     elif case == "grid3d27":
         n, dim = 27, 3
         p0, pf, space = generate_grid_swap(n, seed=17, dim=3)

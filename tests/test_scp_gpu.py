@@ -4,6 +4,7 @@ BASELINE.json's configs 2 and 3."""
 import numpy as np
 import pytest
 
+from oracle import c_oracle as co
 from oracle import qp_oracle as qo
 from oracle import scp_oracle as so
 
@@ -334,6 +335,90 @@ def test_scp_sweep_vs_oracle(kind, n, seed, cg):
     np.testing.assert_allclose(traj["positions"], out["positions"], rtol=0, atol=2e-2 if cg == 1 else 1e-6)
     np.testing.assert_allclose([i["rel_step"] for i in s.last_info["iterations"]], out["rel_steps"], rtol=0.05, atol=2e-3)
     check_solution_properties(s, traj)
+
+
+def test_config4_step_vs_c_oracle():
+    """BASELINE config 4 at full size against the oracle: ONE SCP iteration at 4096 x 50 (419 M collision rows; the joint QP on
+    the lean 16-agent persistent kernel, 256 workgroups = every compute unit) from QP#0's solution, against the C oracle's
+    step from the same x0 (~15 s on one host core): the same working set, the same number of constraint-generation rounds
+    and ADMM iterations, accelerations to 1e-9 (bench.py --agents 4096 reports the measured figure)."""
+    from path_planning.scenarios.position_generator import generate_grid_swap
+    from path_planning.solvers.scp import SCP
+
+    N, K = 4096, 50
+    p0, pf, space = generate_grid_swap(N, seed=1000 * N)
+    s = SCP(N, K * 0.2 + 1e-9, 0.2, 0.8, space, verbose=False)
+    s.set_initial_states(p0)
+    s.set_final_states(pf)
+    s._precompute_constraint_matrices()
+    acc0 = s._solve_initial_trajectory()
+    new, info = s.scp_iteration(acc0)
+    assert info["status_val"] == 1 and "persistent16" in info["pipeline"] and info["persist_gave_up"] == 0
+    prob = so.make_problem(N, K * 0.2 + 1e-9, 0.2, 0.8, space, p0, pf)
+    x0 = acc0.cpu().numpy()
+    pos, _ = co.kinematics(prob, x0)
+    eta, l_col, dist = co.linearize_pairs(prob, pos)
+    x1, io = co.admm(prob, eta, l_col, dist, x0, qo.Settings(max_iter=10000, margin=s.working_set_margin))
+    assert (info["iter"], info["working_rows"], info["rounds"]) == (io["iter"], io["working_rows"], io["rounds"])
+    assert info["rho_updates"] == io["rho_updates"]
+    np.testing.assert_allclose(new.cpu().numpy().reshape(x1.shape), x1, rtol=0, atol=1e-9)
+    # the step on the three-launch pipeline (what every N > 2048 ran before the lean kernel): the same iterates to rounding
+    s3 = SCP(N, K * 0.2 + 1e-9, 0.2, 0.8, space, verbose=False, qp_settings={"persistent": 0})
+    s3.set_initial_states(p0)
+    s3.set_final_states(pf)
+    new3, info3 = s3.scp_iteration(acc0)
+    assert info3["pipeline"] == "three-launch" and info3["iter"] == info["iter"]
+    np.testing.assert_allclose(new.cpu().numpy(), new3.cpu().numpy(), rtol=0, atol=1e-9)
+
+
+def test_carry_rho_follows_the_oracle():
+    """opt-in carry_rho: the joint QP of SCP iteration n + 1 starts at the rho iteration n ended with.  The oracle mirrors it
+    (c_oracle.scp_solve(carry_rho=True)): with two PCG steps the GPU follows it iterate for iterate (equal ADMM counts per
+    QP, waypoints 1e-6), and the result stays within the solver tolerance of the restart-at-0.1 trajectories.  (Whether it
+    SAVES steps depends on the problem -- tools/admm_steps_exp.py measures it; on this case it costs steps.)"""
+    from path_planning.scenarios.position_generator import generate_grid_swap
+
+    n = 96
+    p0, pf, space = generate_grid_swap(n, seed=5)
+    prob = so.make_problem(n, 10.0, 0.2, 0.8, space, p0, pf)
+    st = qo.Settings(max_iter=10000, cg_iters=2)
+    ref = co.scp_solve(prob, 15, st, carry_rho=True)
+    base = co.scp_solve(prob, 15, st, carry_rho=False)
+    s, traj = solve_gpu(n, 10.0, 0.2, 0.8, space, p0, pf, carry_rho=True, qp_settings={"cg_iters": 2})
+    assert s.last_info["n_iterations"] == ref["iterations"]
+    gi = [q["iter"] for q in s.last_info["iterations"]]
+    assert gi == [q["iter"] for q in ref["infos"][1:]], (gi, [q["iter"] for q in ref["infos"][1:]])
+    np.testing.assert_allclose(traj["positions"], ref["positions"], rtol=0, atol=1e-6)
+    assert [q["rho"] for q in s.last_info["iterations"]] == [q["rho"] for q in ref["infos"][1:]]
+    np.testing.assert_allclose(traj["positions"], base["positions"], rtol=0, atol=2e-2)
+
+
+def test_lean_persistent_kernel_full_solves():
+    """Complete solves with the lean 16-agent persistent kernel forced (persistent = 2) at sizes where the 8-agent kernel
+    is the default: both follow the C oracle (SCP iteration count, ADMM counts to a check interval or two, waypoints to the
+    solver tolerance -- the default single-step path, see test_scp_sweep_vs_oracle), and each other much more closely: equal
+    ADMM counts per QP and waypoints to 1e-8 (the two kernels differ in the association of sums only)."""
+    from path_planning.scenarios.position_generator import generate_grid_swap
+
+    for n, seed in ((40, 11), (150, 3)):
+        p0, pf, space = generate_grid_swap(n, seed=seed)
+        prob = so.make_problem(n, 10.0, 0.2, 0.8, space, p0, pf)
+        ref = co.scp_solve(prob, 15, qo.Settings(max_iter=10000))
+        got = {}
+        for lean in (False, True):
+            s, traj = solve_gpu(n, 10.0, 0.2, 0.8, space, p0, pf, qp_settings={"persistent": 2 if lean else 1})
+            assert s.last_info["converged"]
+            want = "persistent16" if lean else "persistent"
+            pipes = [q["pipeline"] for q in s.last_info["iterations"]]
+            assert all(want in q.split("+") for q in pipes), pipes
+            assert s.last_info["n_iterations"] == ref["iterations"]
+            gi = [q["iter"] for q in s.last_info["iterations"]]
+            ci = [q["iter"] for q in ref["infos"][1:]]
+            assert all(abs(a - b) <= 50 for a, b in zip(gi, ci)), (gi, ci)
+            np.testing.assert_allclose(traj["positions"], ref["positions"], rtol=0, atol=2e-2)
+            got[lean] = (gi, traj["positions"])
+        assert got[False][0] == got[True][0], (got[False][0], got[True][0])
+        np.testing.assert_allclose(got[True][1], got[False][1], rtol=0, atol=1e-8)
 
 
 @pytest.mark.parametrize("N", [1024, 4096])

@@ -26,10 +26,34 @@ from path_planning.scenarios.position_generator import generate_grid_swap  # noq
 from path_planning.solvers.scp import SCP  # noqa: E402
 
 
+CLOCKS = []  # profiling build only: MHz the kernel's workgroups ran at (median over the workgroups), one per launch
+
+
+def kernel_mhz(lib, n_wg):
+    """profiling build (SCP_HIP_LIB=.../libscp_hip_prof.so): shader cycles / 100 MHz ticks per workgroup of the latest
+    pairwise kernel -> the clock it ran at"""
+    import ctypes
+
+    if not hasattr(lib, "scp_debug_pair_clocks"):
+        return None
+    n = 2 * min(n_wg, 4096)
+    buf = (ctypes.c_ulonglong * n)()
+    torch.cuda.synchronize()
+    if lib.scp_debug_pair_clocks(buf, n) != 0:
+        return None
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 2).astype(float)
+    a = a[a[:, 1] > 0]
+    return float(np.median(a[:, 0] / a[:, 1]) * 100.0) if len(a) else None
+
+
 def stats(name, xs, rows_bytes):
     xs = np.asarray(xs) * 1e3
+    clk = ""
+    if CLOCKS:
+        clk = f"   kernel clock {np.median(CLOCKS):6.0f} MHz (median of {len(CLOCKS)} launches, min {min(CLOCKS):.0f}, max {max(CLOCKS):.0f})"
+        CLOCKS.clear()
     print(f"{name:58s} n={len(xs):2d}  min {xs.min():7.1f}  median {np.median(xs):7.1f}  mean {xs.mean():7.1f}  max {xs.max():7.1f} us"
-          f"   ({rows_bytes / np.median(xs) / 1e3:6.0f} GB/s at the median)", flush=True)
+          f"   ({rows_bytes / np.median(xs) / 1e3:6.0f} GB/s at the median){clk}", flush=True)
 
 
 def main():
@@ -52,21 +76,39 @@ def main():
     nbytes = pp.rows * 8 * (D + 1) + 2 * N * K * D * 8
     margin = s.working_set_margin
 
+    n_wg = ((pp.nq + 1 + 8191) // 8192) * K
+
+    def clock():
+        c = kernel_mhz(ctx.lib, n_wg)
+        if c is not None:
+            CLOCKS.append(c)
+
     def lin():
         pp.linearize(pos, P0, V0, margin)
+        clock()
         return pp.last_linearize_ms
 
     for _ in range(3):
         lin()
     stats("A back to back", [lin() for _ in range(a.reps)], nbytes)
 
+    s.row_free = False  # (the step on the row-writing kernel, as bench.py times it)
     for _ in range(2):
         s.scp_iteration(acc0)
     xs = []
     for _ in range(a.reps):
         _, info = s.scp_iteration(acc0)
         xs.append(info["linearize_ms"])
-    stats("B inside scp_solver_step", xs, nbytes)
+    # (no clock for B: the last pairwise kernel of a step is its violations pass)
+    stats("B inside scp_solver_step (row-writing)", xs, nbytes)
+    xs = []
+    for _ in range(a.reps):  # B': the same launch sequence as the step's prologue + linearisation, natively, via max_rounds = 0
+        opts = s._native_options()
+        opts.max_rounds = 0
+        _, rec = s._ensure_native().step(s._limits(), s._space(), P0, V0, PF, VF, opts, acc0)
+        clock()
+        xs.append(float(rec.linearize_ms))
+    stats("B' native step cut after the linearisation (max_rounds = 0)", xs, nbytes)
 
     xs = []
     for _ in range(a.reps):

@@ -516,6 +516,7 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.yf = c.take<double>(nf);
   d.wf = c.take<double>(nf);
   d.tf = c.take<double>(nf);
+  d.states = c.take<double>((size_t)4 * C);
   d.x = c.take<double>(nx);
   d.xt = c.take<double>(nx);
   d.rhs = c.take<double>(nx);
@@ -787,7 +788,12 @@ extern "C" void scp_qp_default_settings(scp_qp_settings* s) {
   s->max_iter = 4000;
   s->check_termination = 25;
   s->adaptive_rho = 1;
-  s->adaptive_rho_interval = 25;
+  // OSQP's own default is a wall-clock rule (the first update once the iterations have cost a fraction of the setup time, i.e.
+  // after some multiple of check_termination): not reproducible, and with no factorisation to amortise there is no setup time
+  // to measure.  50 is a measured choice (profiles/r03_rho_interval_sweep.txt: 11 problems, 10 ... 4096 agents): the estimate
+  // after 25 steps overshoots on the large problems (1024 x 50: rho 0.1 -> 0.011, 500 steps; after 50 steps: 250), 75 / 100
+  // cost the small ones.  Total ADMM steps over the sweep 17 225 (25) / 15 500 (50) / 15 500 (75) / 15 950 (100).
+  s->adaptive_rho_interval = 50;
   s->adaptive_rho_tolerance = 5.0;
   s->cg_iters = 1;
   s->use_mfma = 1;
@@ -940,6 +946,16 @@ extern "C" int scp_qp_set_problem(scp_qp* qp, const double* limits, const double
   QP_CHECK(scp_launch_bounds_time_major(qp->ctx, qp->N, qp->K, qp->D, qp->h, limits, space, p0, v0, pf, vf, qp->d.lf,
                                         qp->d.uf));
   memcpy(qp->lim, limits, sizeof(qp->lim));
+  for (int d = 0; d < 3; ++d) {
+    qp->space[d] = d < qp->D ? space[d] : 0.0;
+    qp->space[3 + d] = d < qp->D ? space[qp->D + d] : 0.0;
+  }
+  {
+    const size_t nb = (size_t)qp->C * sizeof(double);
+    const double* src[4] = {p0, v0, pf, vf};
+    for (int i = 0; i < 4; ++i)
+      SCP_HIP_CHECK(qp->ctx, hipMemcpyAsync(qp->d.states + (size_t)i * qp->C, src[i], nb, hipMemcpyDeviceToDevice, qp->ctx->stream));
+  }
   qp->problem_set = true;
   qp->reset_done = false;
   qp->persist_off = false;  // a give-up is a property of the moment (another kernel held the CUs), not of the object
@@ -1211,6 +1227,7 @@ extern "C" int scp_qp_clone_state(scp_qp* dst, const scp_qp* src) {
   const QpDev &a = src->d, &b = dst->d;
 #define CP(field, bytes) SCP_HIP_CHECK(ctx, hipMemcpyAsync(b.field, a.field, (bytes), hipMemcpyDeviceToDevice, s))
   CP(lf, nf); CP(uf, nf); CP(zf, nf); CP(yf, nf); CP(x, nx);
+  CP(states, (size_t)4 * src->C * sizeof(double));
   if (nw) {
     CP(w_row, nw * sizeof(int64_t)); CP(w_k, nw * sizeof(int)); CP(w_i, nw * sizeof(int)); CP(w_j, nw * sizeof(int));
     CP(w_eta, nw * src->D * sizeof(double)); CP(w_l, nw * sizeof(double)); CP(zc, nw * sizeof(double));
@@ -1218,6 +1235,7 @@ extern "C" int scp_qp_clone_state(scp_qp* dst, const scp_qp* src) {
   }
 #undef CP
   memcpy(dst->lim, src->lim, sizeof(dst->lim));
+  memcpy(dst->space, src->space, sizeof(dst->space));
   dst->steps_since_reset = src->steps_since_reset;
   dst->nW = src->nW;
   dst->persist_cap_nW = -1;

@@ -26,6 +26,7 @@ struct QpDev {
   double *T, *pT;  // T = S0 H_f^{-1} (K x K, rebuilt with H_f^{-1}) and its packed form: S0 p = T r without waiting for p
   // fixed rows
   double *lf, *uf, *zf, *yf, *wf, *tf;
+  double* states;  // [4][N][D]: p0, v0, pf, vf of the latest scp_qp_set_problem (the lean persistent kernel re-derives the bounds)
   // x-space vectors [K][C]
   double *x, *xt, *rhs, *r, *p, *zz, *G;
   double* HQ;  // [2K][C]: rows [0,K) = H v, rows [K,2K) = S0 v
@@ -86,6 +87,7 @@ struct scp_qp {
   double* h_scal_dev;  // the same memory as the device sees it: the check kernels write their partials straight to it
   unsigned long long check_seq;  // value the flag takes when the current check has finished
   // persistent single-step kernel (scp_qp_persist.hip)
+  double space[6];                   // {min_0.., max_0..} of the latest scp_qp_set_problem
   double lim[6];                     // {vel, acc, jerk} x {min, max} of the latest scp_qp_set_problem (the lean persistent kernel
                                      // takes the jerk / acceleration bounds as scalars)
   int64_t steps_since_reset;         // ADMM steps since scp_qp_reset: the lean persistent kernel keeps one double per fixed row

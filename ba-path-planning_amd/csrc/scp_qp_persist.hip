@@ -789,7 +789,10 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   a.C = C;
   a.rho = qp->rho; a.rho_c = qp->rho * st.rho_col_scale; a.rho_eq = st.rho_eq_scale; a.alpha = st.alpha; a.h = qp->h;
   a.eps_abs = st.eps_abs; a.eps_rel = st.eps_rel; a.eps_prim_inf = st.eps_prim_inf;
+  a.vel_lo = qp->lim[0]; a.vel_hi = qp->lim[1];
   a.acc_lo = qp->lim[2]; a.acc_hi = qp->lim[3]; a.jerk_lo = qp->lim[4]; a.jerk_hi = qp->lim[5];
+  for (int dd = 0; dd < 3; ++dd) { a.pmin[dd] = qp->space[dd]; a.pmax[dd] = qp->space[3 + dd]; }
+  a.states = d.states;
   a.rho_tol = (st.adaptive_rho && st.adaptive_rho_interval > 0) ? st.adaptive_rho_tolerance : 0.0;
   a.pMinv = d.pMinv;
   a.pT = d.pT;

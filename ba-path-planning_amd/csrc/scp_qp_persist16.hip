@@ -30,13 +30,29 @@ namespace {
 using namespace scpdev;
 using namespace scp_persist;
 
+// Developer build (make prof): 100 MHz wall-clock ticks per phase, summed over the steps of one launch, middle workgroup,
+// thread 0; the accumulators live in LDS (the kernel has no registers to spare).
+#ifdef SCP_PHASE_PROFILE
+__device__ unsigned long long scp_persist16_clk[16];
+#define PSTAMP(slot)                                           \
+  do {                                                         \
+    if (prof_t) {                                              \
+      const unsigned long long now_ = wall_clock64();          \
+      pacc_s[slot] += now_ - pacc_s[15];                       \
+      pacc_s[15] = now_;                                       \
+    }                                                          \
+  } while (0)
+#else
+#define PSTAMP(slot) ((void)0)
+#endif
+
 constexpr int APB16 = 16;          // agents = waves per workgroup
 constexpr int NT16 = 64 * APB16;   // threads
 constexpr int NC16 = 2 * APB16;    // columns of a workgroup (2-D)
 
 struct Lds16 {  // carve-up shared by the kernel and the host's size computation (doubles, then ints)
   int RSK, tK, nks;
-  size_t rt, pt, ml, gp, gchk, ent, n_dbl;
+  size_t rt, pt, ml, gp, ab, gchk, ent, n_dbl;
   __host__ __device__ Lds16(int K, int cap, int nblk) {
     RSK = pad_col(K);
     tK = (K + 15) >> 4;
@@ -46,6 +62,7 @@ struct Lds16 {  // carve-up shared by the kernel and the host's size computation
     pt = o; o += (size_t)NC16 * RSK;
     ml = o; o += (size_t)tK * nks * 64;
     gp = o; o += (size_t)2 * nblk;
+    ab = o; o += (size_t)APB16 * 16;
     // the nine-value all-gather of a termination check reuses the two tiles when they are large enough
     if ((size_t)2 * NC16 * RSK >= (size_t)NCHK * nblk) gchk = rt;
     else { gchk = o; o += (size_t)NCHK * nblk; }
@@ -61,6 +78,14 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
   __shared__ double cert_s[3][APB16];  // per wave: |dy|, support value, |A^T dy| of the batch's last step (fixed rows)
   __shared__ double chk_s[NCHK];       // the nine results of the latest check (read again only at the exit)
   __shared__ int fail_s;
+#ifdef SCP_PHASE_PROFILE
+  __shared__ unsigned long long pacc_s[16];
+  const bool prof_t = blockIdx.x == gridDim.x / 2 && threadIdx.x == 0;
+  if (prof_t) {
+    for (int i = 0; i < 15; ++i) pacc_s[i] = 0;
+    pacc_s[15] = wall_clock64();
+  }
+#endif
   const int K = A.K, N = A.N;
   const int64_t C = A.C;
   const int cap = A.ent_cap, nblk = A.nblk;
@@ -70,6 +95,7 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
   double* Pt = lds + L.pt;            // [32][RSK] p, overwritten in place by the lane's S0 p cell (what the row loops read)
   double* Ml = lds + L.ml;            // [tK][nks][64] packed H_f^{-1}
   double* gp = lds + L.gp;            // [nblk][2] all-gathered line-search partials
+  double* ab = lds + L.ab;            // [16][16] per agent, x D: l_vel, u_vel, vf - v0, pos_min, pos_max, pf, -1e300, +1e300
   double* gck = lds + L.gchk;         // [nblk][9] all-gathered check results
   double* e_c = lds + L.ent;          // [cap][2] signed eta
   double* e_l = e_c + (size_t)cap * D;
@@ -138,7 +164,7 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
 
   // ---- column state: lane k of the agent's wave holds the rows of time step k --------------------------------------
   // row types t = 0 jerk (k < K - 1), 1 acc, 2 vel, 3 pos;  slab row of (t, k): t = 0: k, else t K - 1 + k
-  double v[D][4], lo[D][2], hi[D][2], x[D], c1[D], c2[D];
+  double v[D][4], off[D], x[D], c1[D], c2[D];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const bool rok = t == 0 ? jok : live;
@@ -147,14 +173,50 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       v[d][t] = 0.0;
-      if (t >= 2) lo[d][t - 2] = hi[d][t - 2] = 0.0;
       if (rok) {
         const int64_t g = (int64_t)row * C + (int64_t)agent * D + d;
         v[d][t] = A.zf[g] + A.yf[g] / rr;
-        if (t >= 2) { lo[d][t - 2] = A.lf[g]; hi[d][t - 2] = A.uf[g]; }
       }
     }
   }
+  // The velocity / position bounds of this lane's rows are re-derived where they are needed -- bound_of() of scp_kernels.hip,
+  // the same arithmetic on the same operands (scp.py:212-224, :242-257), so the same bits as the lf / uf slabs -- from 4
+  // registers (the free position of the row's state, k + 1) and eight per-agent scalars in LDS, instead of being held in 16.
+  if (threadIdx.x < APB16 * D) {
+    const int al = threadIdx.x / D, d = threadIdx.x % D, ag = a0 + al;
+    double* o = ab + al * 16;
+    const bool there = ag < N;
+    const double v0 = there ? A.states[((size_t)N + ag) * D + d] : 0.0;
+    o[d] = A.vel_lo - v0;                                                        // l_vel, k < K - 1
+    o[2 + d] = A.vel_hi - v0;                                                    // u_vel
+    o[4 + d] = (there ? A.states[((size_t)3 * N + ag) * D + d] : 0.0) - v0;      // final velocity equality: vf - v0
+    o[6 + d] = A.pmin[d];
+    o[8 + d] = A.pmax[d];
+    o[10 + d] = there ? A.states[((size_t)2 * N + ag) * D + d] : 0.0;            // pf
+    o[12 + d] = -1e300;                                                          // rows beyond the horizon: no bound at all,
+    o[14 + d] = 1e300;                                                           // so that v = 0 stays 0 there
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+#pragma clang fp contract(off)
+    const double p0 = aok ? A.states[(size_t)agent * D + d] : 0.0, v0 = aok ? A.states[((size_t)N + agent) * D + d] : 0.0;
+    const double hk = h * (double)(k + 1);
+    const double hkv = hk * v0;
+    off[d] = p0 + hkv;  // scp.py:246-247
+  }
+  // which table entries bound this lane's velocity / position rows: the inequalities, the final-state equalities
+  // (k = K - 1: lower = upper), or nothing (beyond the horizon) -- an address per lane instead of selects per use
+  const double* const tb = ab + wave * 16;
+  const double* const b_vl = tb + (live ? (lastk ? 4 : 0) : 12);
+  const double* const b_vh = tb + (live ? (lastk ? 4 : 2) : 14);
+  const double* const b_pl = tb + (live ? (lastk ? 10 : 6) : 12);
+  const double* const b_ph = tb + (live ? (lastk ? 10 : 8) : 14);
+  auto bounds = [&](int d, double (&lo)[2], double (&hi)[2]) {
+    lo[0] = b_vl[d];
+    hi[0] = b_vh[d];
+    lo[1] = b_pl[d] - off[d];
+    hi[1] = b_ph[d] - off[d];
+  };
 #pragma unroll
   for (int d = 0; d < D; ++d) {
     x[d] = live ? A.x[(int64_t)k * C + (int64_t)agent * D + d] : 0.0;
@@ -173,6 +235,7 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
   double* my_pt = Pt + (size_t)(wave * D) * RSK + k;   // + d RSK: this lane's slot of column (agent, d)
   double* my_rt = Rt + (size_t)(wave * D) * RSK + k;
 
+  PSTAMP(0);
   bool ok = true;
   int it_done = A.it0;      // ADMM iterations of this solve completed so far
   unsigned steps = 0;       // steps run by this launch
@@ -201,9 +264,11 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         // W' = rho (z - F x) - y with z = Pi(v), y = rho (v - Pi(v))
+        double lo[2], hi[2];
+        bounds(d, lo, hi);
         const double xn = lane_above(x[d]);
         const double cj = fmin(fmax(v[d][0], jlo), jhi), ca = fmin(fmax(v[d][1], alo), ahi);
-        const double cv = fmin(fmax(v[d][2], lo[d][0]), hi[d][0]), cp = fmin(fmax(v[d][3], lo[d][1]), hi[d][1]);
+        const double cv = fmin(fmax(v[d][2], lo[0]), hi[0]), cp = fmin(fmax(v[d][3], lo[1]), hi[1]);
         const double wj = jok ? rho * ((cj - (xn - x[d]) * ih) - (v[d][0] - cj)) : 0.0;
         const double wa = rho * ((ca - x[d]) - (v[d][1] - ca));
         const double wv = rv * ((cv - h * c1[d]) - (v[d][2] - cv));
@@ -220,6 +285,7 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
       }
     }
     __syncthreads();
+    PSTAMP(1);
     // ---- p = H_f^{-1} r on the matrix cores: eight waves = 4 row tiles x 2 column tiles, operands streamed from LDS ----
     if (wave < 8 && (wave & 3) < tK) {
       const int li = lane & 15, lk = lane >> 4;
@@ -241,6 +307,7 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
       }
     }
     __syncthreads();
+    PSTAMP(2);
     // ---- prefix sums of p, S0 p (published where the cell has rows), r.p ------------------------------------------------
     double p[D], s1p[D], s2p[D];
     {
@@ -263,6 +330,7 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
       if (lane == 63) red[0][wave] = rz;
     }
     __syncthreads();
+    PSTAMP(3);
     // ---- working rows: partner cells (polled until they carry this step's tag), eta . d(S0 p) ---------------------------
     {
       double sq = 0.0;
@@ -302,6 +370,7 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
     }
     __syncthreads();
     if (fail_s) { ok = false; break; }
+    PSTAMP(4);
     // ---- all-gather of the two partials of every workgroup -----------------------------------------------------------------
     if (threadIdx.x < 2) {
       double t = 0.0;
@@ -334,6 +403,7 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
     }
     __syncthreads();
     if (fail_s) { ok = false; break; }
+    PSTAMP(5);
     double a;
     {  // every wave sums the partials in the same order: the same bits everywhere, no further barrier
       double vr = 0.0, vs = 0.0;
@@ -347,6 +417,7 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
       a = (pHp > 0.0 && rzt != 0.0) ? rzt / pHp : 0.0;
     }
     const double aa = alpha * a;
+    PSTAMP(6);
     // ---- collision rows first (the certificate of the last step needs their delta-y before the lanes' chain) ----------------
     {
       const double irc = 1.0 / rho_c;
@@ -386,9 +457,11 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
         const double xt = fma(a, p[d], x[d]);
         const double t1 = fma(a, s1p[d], c1[d]), t2 = fma(a, s2p[d], c2[d]);
         const double xtn = lane_above(xt);
+        double lo[2], hi[2];
+        bounds(d, lo, hi);
         // v' = v + alpha (F x~ - Pi(v)); the new z, y are Pi(v'), rho (v' - Pi(v'))
         const double cj = fmin(fmax(v[d][0], jlo), jhi), ca = fmin(fmax(v[d][1], alo), ahi);
-        const double cv = fmin(fmax(v[d][2], lo[d][0]), hi[d][0]), cp = fmin(fmax(v[d][3], lo[d][1]), hi[d][1]);
+        const double cv = fmin(fmax(v[d][2], lo[0]), hi[0]), cp = fmin(fmax(v[d][3], lo[1]), hi[1]);
         const double nj = jok ? fma(alpha, (xtn - xt) * ih - cj, v[d][0]) : v[d][0];
         const double na = fma(alpha, xt - ca, v[d][1]);
         const double nv = fma(alpha, h * t1 - cv, v[d][2]);
@@ -398,11 +471,11 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
           // u.dy+ + l.dy-, and A^T dy by the r chain
           const double dyj = rho * ((nj - fmin(fmax(nj, jlo), jhi)) - (v[d][0] - cj));
           const double dya = rho * ((na - fmin(fmax(na, alo), ahi)) - (v[d][1] - ca));
-          const double dyv = rv * ((nv - fmin(fmax(nv, lo[d][0]), hi[d][0])) - (v[d][2] - cv));
-          const double dyp = rv * ((np - fmin(fmax(np, lo[d][1]), hi[d][1])) - (v[d][3] - cp));
+          const double dyv = rv * ((nv - fmin(fmax(nv, lo[0]), hi[0])) - (v[d][2] - cv));
+          const double dyp = rv * ((np - fmin(fmax(np, lo[1]), hi[1])) - (v[d][3] - cp));
           m_ndy = fmax(m_ndy, fmax(fmax(fabs(dyj), fabs(dya)), fmax(fabs(dyv), fabs(dyp))));
           m_supp += (jhi * fmax(dyj, 0.0) + jlo * fmin(dyj, 0.0)) + (ahi * fmax(dya, 0.0) + alo * fmin(dya, 0.0)) +
-                    (hi[d][0] * fmax(dyv, 0.0) + lo[d][0] * fmin(dyv, 0.0)) + (hi[d][1] * fmax(dyp, 0.0) + lo[d][1] * fmin(dyp, 0.0));
+                    (hi[0] * fmax(dyv, 0.0) + lo[0] * fmin(dyv, 0.0)) + (hi[1] * fmax(dyp, 0.0) + lo[1] * fmin(dyp, 0.0));
           double gd = 0.0;
           for (int e = c0; e < c1e; ++e) gd += e_c[(size_t)e * D + d] * e_pp[(size_t)e * D];
           const double u1 = h * dyv + 0.5 * hh * (dyp - gd);
@@ -428,6 +501,7 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
       if (lane == 63) { cert_s[0][wave] = m_ndy; cert_s[1][wave] = m_supp; cert_s[2][wave] = m_natdy; }
     }
     __syncthreads();
+    PSTAMP(7);
   }
 
   if (!ok) break;
@@ -459,10 +533,12 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
           st_granules(my_cell + 2 * d, ctag, qx);
           my_pt[d * RSK] = qx;
         }
+        double lo[2], hi[2];
+        bounds(d, lo, hi);
         const double xn = lane_above(x[d]);
         const double f[4] = {jok ? (xn - x[d]) * ih : 0.0, x[d], h * c1[d], hh * (c2[d] + 0.5 * c1[d])};
         const double zc[4] = {fmin(fmax(v[d][0], jlo), jhi), fmin(fmax(v[d][1], alo), ahi),
-                              fmin(fmax(v[d][2], lo[d][0]), hi[d][0]), fmin(fmax(v[d][3], lo[d][1]), hi[d][1])};  // z = Pi(v)
+                              fmin(fmax(v[d][2], lo[0]), hi[0]), fmin(fmax(v[d][3], lo[1]), hi[1])};  // z = Pi(v)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           if (t == 0 ? jok : live) {
@@ -619,8 +695,10 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
             const double ratio = rho / nrs;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
+              double lo[2], hi[2];
+              bounds(d, lo, hi);
               const double zc[4] = {fmin(fmax(v[d][0], jlo), jhi), fmin(fmax(v[d][1], alo), ahi),
-                                    fmin(fmax(v[d][2], lo[d][0]), hi[d][0]), fmin(fmax(v[d][3], lo[d][1]), hi[d][1])};
+                                    fmin(fmax(v[d][2], lo[0]), hi[0]), fmin(fmax(v[d][3], lo[1]), hi[1])};
 #pragma unroll
               for (int t = 0; t < 4; ++t) v[d][t] = fma(v[d][t] - zc[t], ratio, zc[t]);
             }
@@ -639,6 +717,7 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
       }
     }
     __syncthreads();  // Rt zeroed, operands / row values of a new rho in place
+    PSTAMP(9);
   }
   }  // batches
 
@@ -658,9 +737,11 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
   for (int d = 0; d < D; ++d) {
     const double xn = lane_above(x[d]);
     const double c1b = lane_below(c1[d]);
+    double lo[2], hi[2];
+    bounds(d, lo, hi);
     const double f[4] = {(xn - x[d]) * ih, x[d], h * c1[d], hh * (c2[d] + 0.5 * c1[d])};
     const double zc[4] = {fmin(fmax(v[d][0], jlo), jhi), fmin(fmax(v[d][1], alo), ahi),
-                          fmin(fmax(v[d][2], lo[d][0]), hi[d][0]), fmin(fmax(v[d][3], lo[d][1]), hi[d][1])};
+                          fmin(fmax(v[d][2], lo[0]), hi[0]), fmin(fmax(v[d][3], lo[1]), hi[1])};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (t == 0 ? jok : live) {
@@ -685,6 +766,11 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
       A.yc[n] = e_y[e];
     }
   }
+  PSTAMP(8);
+#ifdef SCP_PHASE_PROFILE
+  if (prof_t)
+    for (int i = 0; i < 16; ++i) scp_persist16_clk[i] = i == 15 ? (unsigned long long)steps : pacc_s[i];
+#endif
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // the nine check results in the slots the host reads (scp_qp::h_scal), then the exit code and the completion word
     const int slot[NCHK] = {SL_RP, SL_NAX, SL_NZ, SL_RD, SL_NPX, SL_NATY, SL_NDY, SL_SUPP, SL_NATDY};
@@ -700,6 +786,14 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
 }
 
 }  // namespace
+
+#ifdef SCP_PHASE_PROFILE
+// developer hook of the profiling build only (not declared in include/scp_hip.h)
+extern "C" int scp_debug_persist16_clocks(unsigned long long* out, int n) {
+  if (n > 16) n = 16;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(scp_persist16_clk), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 size_t scp_persist16_lds_bytes(int K, int cap, int nblk) {
   const Lds16 L(K, cap, nblk);

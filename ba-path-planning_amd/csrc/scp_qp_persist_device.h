@@ -16,7 +16,10 @@ struct PersistArgs {
   int64_t C;
   double rho, rho_c, rho_eq, alpha, h;
   double eps_abs, eps_rel, eps_prim_inf, rho_tol;  // termination tests (eps_prim_inf <= 0: no certificate; rho_tol <= 0: fixed rho)
-  double jerk_lo, jerk_hi, acc_lo, acc_hi;  // the bounds of the jerk / acceleration rows (the same for every row; lean kernel)
+  // lean kernel: the bounds of the jerk / acceleration rows (the same for every row), and what the velocity / position
+  // bounds are made of (scp_qp_set_problem keeps a copy of the four state arrays: [4][N][D] = p0, v0, pf, vf)
+  double jerk_lo, jerk_hi, acc_lo, acc_hi, vel_lo, vel_hi, pmin[3], pmax[3];
+  const double* states;
   const double* pMinv;
   const double* pT;      // packed T = S0 H_f^{-1}
   const double *lf, *uf;

@@ -26,6 +26,8 @@ def build_parser():
     p.add_argument("--max-iterations", type=int, default=15)
     p.add_argument("--polish", action="store_true",
                    help="one more joint QP at 1e-8 after the SCP loop: the result meets every constraint to ~1e-6")
+    p.add_argument("--cg-iters", type=int, default=None,
+                   help="PCG steps per ADMM step of the joint QP (scp_qp_settings.cg_iters; default 1)")
     p.add_argument("--no-plots", action="store_true")
     p.add_argument("--save-prefix", default=None, help="write <prefix>_2d.pdf and <prefix>_snapshots.pdf")
     return p
@@ -66,6 +68,7 @@ def main(argv=None):
             space_dims=space_dims,
             dim=args.dim,
             polish=args.polish,
+            qp_settings={"cg_iters": args.cg_iters} if args.cg_iters else None,
         )
         print(f"Successfully generated positions for {n_vehicles} vehicles")
         solver.set_initial_states(np.asarray(initial_positions))

@@ -63,7 +63,8 @@ typedef struct scp_qp_settings {
   int32_t max_iter;              /* 4000 (QP#0, scp.py:360) / 10000 (scp.py:442) */
   int32_t check_termination;     /* 25 */
   int32_t adaptive_rho;          /* 1 */
-  int32_t adaptive_rho_interval; /* 25 (iterations; multiple of check_termination) */
+  int32_t adaptive_rho_interval; /* 50 (iterations; a multiple of check_termination.  OSQP's default is a wall-clock rule;
+                                    50 is the measured choice of profiles/r03_rho_interval_sweep.txt) */
   double adaptive_rho_tolerance; /* 5 */
   int32_t cg_iters;              /* 1: PCG steps per ADMM step (fixed count >= 1, warm started at x) */
   int32_t use_mfma;              /* 1: fused column-block kernels, every K-dimension product on

@@ -196,7 +196,7 @@ class Settings:
     max_iter: int = 4000
     check_termination: int = 25
     adaptive_rho: bool = True
-    adaptive_rho_interval: int = 25
+    adaptive_rho_interval: int = 50  # (scp_qp_default_settings: a measured choice, see there)
     adaptive_rho_tolerance: float = 5.0
     cg_iters: int = 1         # PCG steps per ADMM step (fixed count; warm started at x)
     cg_tol: float = 0.0       # optional early exit: ||r||_2 <= cg_tol * ||rhs||_2

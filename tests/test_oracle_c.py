@@ -47,9 +47,13 @@ def test_c_admm_vs_numpy(n, seed, T, h):
     np.testing.assert_allclose(xc, x0, rtol=0, atol=1e-9)
     pos, _ = so.kinematics(prob, x0)
     eta, l_col, dist = so.linearize_pairs(prob, pos)
-    st = qo.Settings(max_iter=10000)
-    x1, _, i1 = qo.admm_structured(prob, eta, l_col, dist, x0=x0, st=st)
-    xc, ic = co.admm(prob, eta, l_col, dist, x0, st)
-    assert ic["status_val"] == i1["status_val"] and ic["iter"] == i1["iter"] and ic["rounds"] == i1["rounds"]
-    assert ic["working_rows"] == i1["working_rows"]
-    np.testing.assert_allclose(xc, x1, rtol=0, atol=1e-8)
+    # two PCG steps: iterate for iterate; the default single step is not contractive during the transient and can amplify the
+    # 1e-16 between two summation orders (numpy einsum vs C loops) by up to 1e7 on small, nearly degenerate QPs before both
+    # converge to the same point: the same counts, waypoints to 1e-6
+    for cg, tol in ((2, 1e-9), (1, 1e-6)):
+        st = qo.Settings(max_iter=10000, cg_iters=cg)
+        x1, _, i1 = qo.admm_structured(prob, eta, l_col, dist, x0=x0, st=st)
+        xc, ic = co.admm(prob, eta, l_col, dist, x0, st)
+        assert ic["status_val"] == i1["status_val"] and ic["iter"] == i1["iter"] and ic["rounds"] == i1["rounds"]
+        assert ic["working_rows"] == i1["working_rows"]
+        np.testing.assert_allclose(xc, x1, rtol=0, atol=tol)

@@ -24,7 +24,8 @@ COLA = ["prologue: operand prefetch, x / F x / z / y, gather G", "r: reverse sca
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     p0, pf, space = generate_grid_swap(N, seed=1000 * N, dim=2, block=4, min_sep=0.3)
-    s = SCP(N, 10.0, 0.2, 0.8, space, dim=2, verbose=False)
+    qp = {"persistent": int(sys.argv[2])} if len(sys.argv) > 2 else None  # 2: the lean 16-agent kernel at any size
+    s = SCP(N, 10.0, 0.2, 0.8, space, dim=2, verbose=False, qp_settings=qp)
     s.set_initial_states(p0)
     s.set_final_states(pf)
     s._precompute_constraint_matrices()
@@ -44,6 +45,19 @@ def main():
             v = pb[i] * 0.01
             print(f"  {name:44s} {v if i in (0, 8) else v / steps:8.2f} us{' (total)' if i in (0, 8) else ''}")
         print(f"  {'sum':44s} {sum(pb) * 0.01:8.2f} us per launch")
+    if hasattr(lib, "scp_debug_persist16_clocks") and lib.scp_debug_persist16_clocks(pb, 16) == 0 and sum(pb):
+        names = ["state load (once per launch)", "gather G, W', r: suffix scans", "p = Minv r (MFMA, operands from LDS)",
+                 "prefix sums of p, S0 p, publish cells", "rows: poll partner cells, eta . dS0p", "all-gather of the partials",
+                 "step length", "updates (entries, then registers)", "state write-back (once per launch)", "termination checks (total)"]
+        steps = max(int(pb[15]), 1)
+        pb[15] = 0
+        print(f"cg1_persist16_kernel (lean), middle workgroup, last launch ({steps} steps), us per step:")
+        for i, name in enumerate(names):
+            v = pb[i] * 0.01
+            once = i in (0, 8, 9)
+            print(f"  {name:44s} {v if once else v / steps:8.2f} us{' (total)' if once else ''}")
+        print(f"  {'sum':44s} {sum(pb) * 0.01:8.2f} us per launch")
+        return
     buf = (C.c_ulonglong * 64)()
     assert lib.scp_debug_phase_clocks(buf, 64) == 0
     t = list(buf)

@@ -26,6 +26,7 @@
 #include "scp_qp_persist_device.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cerrno>
 #include <chrono>
 
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(64 * persist_apb(D)) void cg1_persist_kernel(Persis
             bad = true;
             break;
           }
-          __builtin_amdgcn_s_sleep(1);
+          spin_nap(A.spin_sleep);
         }
         if (bad) break;
         double s = 0.0;
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(64 * persist_apb(D)) void cg1_persist_kernel(Persis
             bad = true;
             break;
           }
-          __builtin_amdgcn_s_sleep(1);
+          spin_nap(A.spin_sleep);
         }
         if (bad) break;
         gp[q] = pair_value(w);
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(64 * persist_apb(D)) void cg1_persist_kernel(Persis
             bad = true;
             break;
           }
-          __builtin_amdgcn_s_sleep(1);
+          spin_nap(A.spin_sleep);
         }
         if (bad) break;
         double ax = 0.0;
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(64 * persist_apb(D)) void cg1_persist_kernel(Persis
             bad = true;
             break;
           }
-          __builtin_amdgcn_s_sleep(1);
+          spin_nap(A.spin_sleep);
         }
         if (bad) break;
         gp[q] = pair_value(w);
@@ -793,6 +794,14 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   a.acc_lo = qp->lim[2]; a.acc_hi = qp->lim[3]; a.jerk_lo = qp->lim[4]; a.jerk_hi = qp->lim[5];
   for (int dd = 0; dd < 3; ++dd) { a.pmin[dd] = qp->space[dd]; a.pmax[dd] = qp->space[3 + dd]; }
   a.states = d.states;
+  {
+    static const int spin_sleep = [] {  // developer knob (tools/batch_rate.sh experiments)
+      const char* e = getenv("SCP_PERSIST_SPIN_SLEEP");
+      const int v = e ? atoi(e) : 1;
+      return v < 1 ? 1 : (v > 64 ? 64 : v);
+    }();
+    a.spin_sleep = spin_sleep;
+  }
   a.rho_tol = (st.adaptive_rho && st.adaptive_rho_interval > 0) ? st.adaptive_rho_tolerance : 0.0;
   a.pMinv = d.pMinv;
   a.pT = d.pT;
@@ -802,6 +811,7 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   a.cells = d.cells;
   a.gpart = d.gpart;
   a.gcheck = d.gcheck;
+  a.gsum = d.gsum;
   a.give_up = (unsigned*)d.sync_words;
   a.cell_ptr = d.cell_ptr; a.ent_code = d.ent_code; a.w_k = d.w_k; a.w_i = d.w_i; a.w_j = d.w_j;
   a.w_eta = d.w_eta; a.w_l = d.w_l; a.zc = d.zc; a.yc = d.yc; a.dyc = d.dyc; a.gval = d.gval;
@@ -830,6 +840,7 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
     SCP_HIP_CHECK(ctx, hipMemsetAsync(d.cells, 0, (size_t)K * C * 2 * sizeof(u64), s));
     SCP_HIP_CHECK(ctx, hipMemsetAsync(d.gpart, 0, (size_t)SCP_GPART_WORDS * sizeof(u64), s));
     SCP_HIP_CHECK(ctx, hipMemsetAsync(d.gcheck, 0, (size_t)SCP_GCHECK_WORDS * sizeof(u64), s));
+    SCP_HIP_CHECK(ctx, hipMemsetAsync(d.gsum, 0, (size_t)SCP_GSUM_WORDS * sizeof(u64), s));
     qp->persist_epoch = 0;
   }
   a.epoch0 = (unsigned)qp->persist_epoch;

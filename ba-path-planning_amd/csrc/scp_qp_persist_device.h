@@ -20,6 +20,8 @@ struct PersistArgs {
   // bounds are made of (scp_qp_set_problem keeps a copy of the four state arrays: [4][N][D] = p0, v0, pf, vf)
   double jerk_lo, jerk_hi, acc_lo, acc_hi, vel_lo, vel_hi, pmin[3], pmax[3];
   const double* states;
+  int spin_sleep;  // naps (64 clocks each) between two polls of a granule that has not arrived (1; more when many persistent
+                   // launches share the chip: their polls load the fabric the hand-offs travel on)
   const double* pMinv;
   const double* pT;      // packed T = S0 H_f^{-1}
   const double *lf, *uf;
@@ -27,6 +29,8 @@ struct PersistArgs {
   u64* cells;       // [K][N][D][2] granules: S0 p of (time step, agent), low / high word, each tagged with the step
   u64* gpart;       // [2 parities][nblk][4] granules: r.p and sum (eta . d S0 p)^2 of one workgroup
   u64* gcheck;      // [nblk][18] granules: the nine partial results of a termination check of one workgroup
+  u64* gsum;        // [2 parities][SCP_PERSIST_MAX_GROUPS][4] granules: the two partials summed over a group of workgroups
+                    // (two-level all-reduce of the lean kernel)
   unsigned* give_up;
   const int *cell_ptr, *ent_code, *w_k, *w_i, *w_j;
   const double *w_eta, *w_l;
@@ -79,6 +83,9 @@ __device__ inline void ld_cell(const u64* g, u32x4 (&w)[D]) {  // the D doubles 
 #pragma unroll
     for (int d = 0; d < D; ++d) w[d] = ld_pair(g + 2 * d);
   }
+}
+__device__ inline void spin_nap(int n) {
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
 }
 __device__ inline bool pair_ok(const u32x4& w, unsigned tag) { return w[1] == tag && w[3] == tag; }
 __device__ inline double pair_value(const u32x4& w) { return __hiloint2double((int)w[2], (int)w[0]); }

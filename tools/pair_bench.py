@@ -33,6 +33,11 @@ def main():
         rows, md, fv = pp.linearize(pos_t, p0_t, v0_t, a.margin)
         ms = pp.last_linearize_ms
         print(f"linearize  {ms*1e3:8.1f} us  {pp.rows*bytes_row/ms/1e6:8.1f} GB/s  sel={rows.numel()} min={md:.4f}")
+    for r in range(a.reps):  # the row-free form of the same pass (scp_select_pairs): same selection, no row stream
+        rows, md, fv = pp.select(pos_t, a.margin)
+        ms = pp.last_linearize_ms
+        print(f"select     {ms*1e3:8.1f} us  {pp.rows/ms/1e6:8.1f} G rows/s  sel={rows.numel()} min={md:.4f}")
+    rows, md, fv = pp.linearize(pos_t, p0_t, v0_t, a.margin)  # (the violations pass works on the bitmap of a linearisation)
     for r in range(a.reps):
         pp.bitmap.zero_()
         new, mv = pp.violations(pos_t, p0_t, v0_t, 1e-6)

@@ -14,10 +14,10 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
-PFX = "r02_"
+PFX = os.environ.get("PFX", "r03_")
 
 COPIES = {
     "bench_n1024.json": "bench_n1024.json", "bench_n1024_kernel_stats.csv": "bench_n1024_kernel_stats.csv",
@@ -27,6 +27,12 @@ COPIES = {
     "batch128_rates.txt": "batch128_rates.txt", "batch128_cold.txt": "batch128_cold.txt", "demo_k500.txt": "demo_k500.txt",
     "grid_sync_bench.txt": "grid_sync_bench.txt", "solve128.txt": "solve128.txt",
     "solve128_kernel_stats.csv": "solve128_kernel_stats.csv",
+    "bench_n4096_1gpu_kernel_stats.csv": "bench_n4096_1gpu_kernel_stats.csv",
+    "phase_profile_lean_n4096.txt": "phase_profile_lean_n4096.txt", "step_time.txt": "step_time.txt",
+    "bench_n1024_under_rocprof.json": "bench_n1024_under_rocprof.json",
+    "rehearsal_2ranks_gloo_n1024.json": "rehearsal_2ranks_gloo_n1024.json",
+    "rehearsal_2ranks_gloo_n4096.json": "rehearsal_2ranks_gloo_n4096.json",
+    "pair_context_clock_1024.txt": "pair_context_clock_1024.txt", "membw.txt": "membw.txt",
 }
 for a, b in COPIES.items():
     pa = os.path.join(src, a)
@@ -35,7 +41,7 @@ for a, b in COPIES.items():
     else:
         print("missing:", a)
 
-OURS = ("pair_pass_kernel", "cg1_", "qp0_col", "compact_", "csr_", "pair_prep", "qp_reset", "kinematics", "rows_value",
+OURS = ("pair_pass_kernel", "cg1_", "add_rows_at", "qp0_col", "compact_", "csr_", "pair_prep", "qp_reset", "kinematics", "rows_value",
         "add_rows", "spd_inverse", "gemm_f64", "pack_operands", "build_hf", "rel_step", "check_done")
 
 
@@ -78,7 +84,8 @@ N, K, D = 1024, 50, 2
 rows_n = N * (N - 1) // 2 * K
 kinds = {"linearize": ("pair_pass_kernel<2, 0,", rows_n * 8 * (D + 1) + 2 * N * K * D * 8),
          "violations_recompute": ("pair_pass_kernel<2, 3,", 2 * N * K * D * 8),
-         "check": ("pair_pass_kernel<2, 1,", 2 * N * K * D * 8)}
+         "check": ("pair_pass_kernel<2, 1,", 2 * N * K * D * 8),
+         "select": ("pair_pass_kernel<2, 4,", N * K * D * 8)}
 out = {
     "source": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes, --kernel-trace only) -- python3 "
               "tools/pair_bench.py --reps 3; 1024 agents x 50 steps, D=2 (tools/collect_profiles.sh, "

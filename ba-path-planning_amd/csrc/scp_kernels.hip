@@ -75,11 +75,15 @@ hipError_t scp_raise_lds_limit(int device, const void* kernel, size_t bytes) {
 
 static std::atomic<int> g_host_wait_mode{0};
 
-extern "C" void scp_set_host_wait(int mode) { g_host_wait_mode.store(mode == 1 ? 1 : 0, std::memory_order_relaxed); }
+extern "C" void scp_set_host_wait(int mode) {
+  g_host_wait_mode.store(mode == 1 || mode == 2 ? mode : 0, std::memory_order_relaxed);
+}
 
 bool scp_wait_host_word(volatile unsigned long long* word, unsigned long long seq, int timeout_s) {
   const auto t0 = std::chrono::steady_clock::now();
-  const bool sleepy = g_host_wait_mode.load(std::memory_order_relaxed) == 1;
+  const int wait_mode = g_host_wait_mode.load(std::memory_order_relaxed);
+  const bool sleepy = wait_mode != 0;
+  const unsigned spin_first = wait_mode == 2 ? 0u : 2000u;  // mode 2: nap at once (more solver threads than cores)
   if (sleepy) {
     // the kernel's default timer slack (50 us) would stretch every 20 us nap to ~75 us -- a third of a 25-step persistent
     // launch; 1 us of slack for this thread
@@ -95,7 +99,7 @@ bool scp_wait_host_word(volatile unsigned long long* word, unsigned long long se
     __builtin_ia32_pause();
 #endif
     ++spins;
-    if (sleepy && spins > 2000) {  // ~20 us of spinning: the kernel is a long one, give the core away
+    if (sleepy && spins > spin_first) {  // mode 1: ~20 us of spinning first: the kernel is a long one, give the core away
       struct timespec ts = {0, 20000};
       nanosleep(&ts, nullptr);
       if ((spins & 0x3FF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s)) break;

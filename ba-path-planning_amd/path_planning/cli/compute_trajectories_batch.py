@@ -200,6 +200,9 @@ def build_parser():
                    help="scp_qp_settings.persistent: 1 = persistent ADMM kernel with 8 agents per workgroup (default), 2 = its "
                         "lean 16-agent form (half the compute units per solve: more solves side by side), 0 = three launches "
                         "per ADMM step")
+    p.add_argument("--host-wait", type=int, choices=[0, 1, 2], default=None,
+                   help="how worker threads wait for the GPU (scp_set_host_wait): 0 spin, 1 spin 20 us then nap (default with "
+                        "--streams > 1 or several ranks), 2 nap at once (more workers than host cores)")
     p.add_argument("--carry-rho", action="store_true",
                    help="every joint QP after the first starts at the rho the previous SCP iteration ended with")
     p.add_argument("--streams", type=int, default=1,
@@ -232,7 +235,11 @@ def main(argv=None):
         # many solver threads / processes on the host's cores: waiting threads sleep between polls instead of spinning
         from .. import _hip
 
-        _hip.load_library().scp_set_host_wait(1)
+        _hip.load_library().scp_set_host_wait(1 if args.host_wait is None else args.host_wait)
+    elif args.host_wait is not None:
+        from .. import _hip
+
+        _hip.load_library().scp_set_host_wait(args.host_wait)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         # more ranks than GPUs is a feature: launches of one process serialise in the HIP runtime (8 streams in ONE

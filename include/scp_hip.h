@@ -114,7 +114,8 @@ typedef enum scp_qp_pipeline {
 
 int scp_abi_version(void);
 /* How host threads wait for a kernel's completion word (process-wide): 0 = spin (default: lowest latency, one core per
- * waiting thread), 1 = spin ~20 us, then poll from 20 us sleeps (many solver threads on few cores). */
+ * waiting thread), 1 = spin ~20 us, then poll from 20 us sleeps (many solver threads on few cores), 2 = sleep between polls
+ * from the first miss (more solver threads than cores). */
 void scp_set_host_wait(int mode);
 
 /* Plane stride (in doubles) of the SoA eta array of scp_linearize_pairs: K*nq rounded up to an even count so

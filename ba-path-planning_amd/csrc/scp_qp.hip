@@ -554,7 +554,6 @@ size_t carve(QpDev& d, void* ws, int K, int64_t C, int64_t cap, int D) {
   d.cells = c.take<unsigned long long>((size_t)2 * nx);
   d.gpart = c.take<unsigned long long>(SCP_GPART_WORDS);
   d.gcheck = c.take<unsigned long long>(SCP_GCHECK_WORDS);
-  d.gsum = c.take<unsigned long long>(SCP_GSUM_WORDS);
   return c.off;
 }
 

@@ -56,7 +56,6 @@ struct QpDev {
   unsigned long long* cells;       // [K][N][D][2] tagged granules: S0 p cells published by the persistent kernel
   unsigned long long* gpart;       // SCP_GPART_WORDS tagged granules: line-search partials, two alternating buffers
   unsigned long long* gcheck;      // SCP_GCHECK_WORDS tagged granules: termination-check partials
-  unsigned long long* gsum;        // SCP_GSUM_WORDS tagged granules: group sums of the line-search partials (lean kernel)
 };
 
 struct scp_qp {
@@ -137,9 +136,6 @@ constexpr int SCP_SYNC_WORDS = 16;  // u64: give-up word | scratch
 constexpr int SCP_PERSIST_MAX_WG = 256;
 constexpr int SCP_GPART_WORDS = 2 * (SCP_PERSIST_MAX_WG + 1) * 4;  // two buffers x workgroups x two doubles as granule pairs
 constexpr int SCP_GCHECK_WORDS = (SCP_PERSIST_MAX_WG + 1) * 9 * 2;  // nine check results per workgroup as granule pairs
-constexpr int SCP_PERSIST_GROUP = 16;       // workgroups per group of the two-level all-reduce (lean kernel)
-constexpr int SCP_PERSIST_MAX_GROUPS = 32;  // >= (SCP_PERSIST_MAX_WG + 1) / SCP_PERSIST_GROUP
-constexpr int SCP_GSUM_WORDS = 2 * SCP_PERSIST_MAX_GROUPS * 4;
 bool scp_qp_persist_eligible(const scp_qp* qp);
 // Compute units claimed by the persistent launches in flight on one device of THIS process (solver threads on several
 // streams, compute-trajectories-batch): a launch needs all its workgroups resident at once, so it first claims one CU per

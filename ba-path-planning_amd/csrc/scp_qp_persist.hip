@@ -811,7 +811,6 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   a.cells = d.cells;
   a.gpart = d.gpart;
   a.gcheck = d.gcheck;
-  a.gsum = d.gsum;
   a.give_up = (unsigned*)d.sync_words;
   a.cell_ptr = d.cell_ptr; a.ent_code = d.ent_code; a.w_k = d.w_k; a.w_i = d.w_i; a.w_j = d.w_j;
   a.w_eta = d.w_eta; a.w_l = d.w_l; a.zc = d.zc; a.yc = d.yc; a.dyc = d.dyc; a.gval = d.gval;
@@ -840,7 +839,6 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
     SCP_HIP_CHECK(ctx, hipMemsetAsync(d.cells, 0, (size_t)K * C * 2 * sizeof(u64), s));
     SCP_HIP_CHECK(ctx, hipMemsetAsync(d.gpart, 0, (size_t)SCP_GPART_WORDS * sizeof(u64), s));
     SCP_HIP_CHECK(ctx, hipMemsetAsync(d.gcheck, 0, (size_t)SCP_GCHECK_WORDS * sizeof(u64), s));
-    SCP_HIP_CHECK(ctx, hipMemsetAsync(d.gsum, 0, (size_t)SCP_GSUM_WORDS * sizeof(u64), s));
     qp->persist_epoch = 0;
   }
   a.epoch0 = (unsigned)qp->persist_epoch;

@@ -371,49 +371,23 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
     __syncthreads();
     if (fail_s) { ok = false; break; }
     PSTAMP(4);
-    // ---- all-reduce of the two partials of every workgroup, in TWO levels -------------------------------------------------
-    // 256 workgroups that each poll all 512 partials load the fabric the granules travel on (4.1 us per step, measured);
-    // here the first workgroup of every group of 16 sums its group's partials (32 polls) and publishes the group sums, and
-    // everybody polls those (2 x 16 values): two hand-offs in sequence, a sixteenth of the traffic.  The summation order is
-    // fixed (butterfly inside a group, then index order over the groups): the same bits in every workgroup.
+    // ---- all-gather of the two partials of every workgroup -----------------------------------------------------------------
+    // (A two-level form -- group leaders sum 16 partials, everybody polls 16 group sums: a sixteenth of the polls -- was
+    // measured at 4096 x 50 and is SLOWER, 4.8 against 4.0 us: what this phase waits for is the slowest workgroup of the
+    // step, not the fabric.)
     if (threadIdx.x < 2) {
       double t = 0.0;
 #pragma unroll
       for (int w = 0; w < APB16; ++w) t += red[threadIdx.x][w];
       st_granules(gpart + (size_t)blockIdx.x * 4 + 2 * threadIdx.x, tag, t);
     }
-    const int ngrp = (nblk + SCP_PERSIST_GROUP - 1) / SCP_PERSIST_GROUP;
-    u64* gsum = A.gsum + (size_t)(tag & 1u) * SCP_PERSIST_MAX_GROUPS * 4;
     {
       unsigned spins = 0;
       bool bad = false;
-      if (blockIdx.x % SCP_PERSIST_GROUP == 0 && wave == 0) {  // this group's leader, one wave: lane = (member, which)
-        const int grp = blockIdx.x / SCP_PERSIST_GROUP;
-        const int member = grp * SCP_PERSIST_GROUP + (lane >> 1);
-        double val = 0.0;
-        if (lane < 2 * SCP_PERSIST_GROUP && member < nblk) {
-          u32x4 w;
-          for (;;) {
-            w = ld_pair(gpart + 2 * (size_t)(member * 2 + (lane & 1)));
-            if (pair_ok(w, tag)) break;
-            if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
-                                         __hip_atomic_load(A.give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-              bad = true;
-              break;
-            }
-            spin_nap(A.spin_sleep);
-          }
-          if (!bad) val = pair_value(w);
-        }
-#pragma unroll
-        for (int o = 2; o < 2 * SCP_PERSIST_GROUP; o <<= 1) val += __shfl_xor(val, o);  // over the members, `which` apart
-        if (__any(bad)) bad = true;
-        if (!bad && lane < 2) st_granules(gsum + (size_t)(grp * 2 + lane) * 2, tag, val);
-      }
-      for (int q = threadIdx.x; q < 2 * ngrp && !bad; q += NT16) {  // the group sums: one double per thread
+      for (int q = threadIdx.x; q < 2 * nblk; q += NT16) {  // one double (two granules) per thread and pass
         u32x4 w;
         for (;;) {
-          w = ld_pair(gsum + 2 * q);
+          w = ld_pair(gpart + 2 * q);
           if (pair_ok(w, tag)) break;
           if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
                                        __hip_atomic_load(A.give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
@@ -434,8 +408,12 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
     if (fail_s) { ok = false; break; }
     PSTAMP(5);
     double a;
-    {  // every wave sums the group sums in the same order: the same bits everywhere, no further barrier
-      const double vr = lane < ngrp ? gp[2 * lane] : 0.0, vs = lane < ngrp ? gp[2 * lane + 1] : 0.0;
+    {  // every wave sums the partials in the same order: the same bits everywhere, no further barrier
+      double vr = 0.0, vs = 0.0;
+      for (int b = lane; b < nblk; b += 64) {
+        vr += gp[2 * b];
+        vs += gp[2 * b + 1];
+      }
       const double rzt = read_lane(wave_incl_sum(vr), 63);
       const double sqt = read_lane(wave_incl_sum(vs), 63);
       const double pHp = rzt + rho_c * sqt;

@@ -29,8 +29,6 @@ struct PersistArgs {
   u64* cells;       // [K][N][D][2] granules: S0 p of (time step, agent), low / high word, each tagged with the step
   u64* gpart;       // [2 parities][nblk][4] granules: r.p and sum (eta . d S0 p)^2 of one workgroup
   u64* gcheck;      // [nblk][18] granules: the nine partial results of a termination check of one workgroup
-  u64* gsum;        // [2 parities][SCP_PERSIST_MAX_GROUPS][4] granules: the two partials summed over a group of workgroups
-                    // (two-level all-reduce of the lean kernel)
   unsigned* give_up;
   const int *cell_ptr, *ent_code, *w_k, *w_i, *w_j;
   const double *w_eta, *w_l;

@@ -12,8 +12,9 @@ Differences to the reference that a caller can observe (INTEGRATION.md has the f
   * ``_add_collision_constraints`` returns the compact form (eta, l) of the constraint rows instead of a
     2.6e9-non-zero CSC matrix; ``C_jerk/C_acc/C_vel/C_pos`` are not materialised (they stay None);
   * new keyword-only arguments: ``dim`` (2 or 3), ``device``, ``qp_settings``, ``working_set_margin``,
-    ``feasibility_tol``, ``max_rounds``, ``refresh_feasibility``, ``polish``/``polish_eps``, ``native``, ``qp_row_capacity``, ``verbose``,
-    ``rank``/``world_size``/``group`` (agent-sharded multi-GPU).
+    ``feasibility_tol``, ``max_rounds``, ``refresh_feasibility``, ``polish``/``polish_eps``, ``native``, ``row_free``, ``carry_rho``,
+    ``qp_row_capacity``, ``verbose``, ``rank``/``world_size``/``group`` (pair-range-sharded multi-GPU: the SCP iteration natively,
+    split at its exchange points -- ``scp_iteration_sharded``).
 """
 from __future__ import annotations
 

@@ -1106,7 +1106,7 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
       } else if (ran) {
         ++info->persist_launches;
         info->rho_switches_in_kernel += qp->persist_rho_switches;
-        pipes |= 1 << (qp->persist_variant ? SCP_PIPE_PERSIST16 : SCP_PIPE_PERSIST);
+        pipes |= 1 << (qp->persist_variant == 1 ? SCP_PIPE_PERSIST16 : (qp->persist_variant == 2 ? SCP_PIPE_PERSIST8L : SCP_PIPE_PERSIST));
         cg_total += it_done - it;
         qp->steps_since_reset += it_done - it;
         it = it_done;

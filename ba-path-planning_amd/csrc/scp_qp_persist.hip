@@ -704,18 +704,24 @@ size_t persist_lds_bytes(int K, int D, int cap, int nblk) {
 }  // namespace
 
 // Can the persistent kernel run this QP?  (shape limits; the entry capacity is checked per working set)
-// which kernel runs this shape: 0 = one wave per agent with 8 (3-D: 4) agents per workgroup, 1 = the lean 16-agent kernel
-// (2-D; taken when the blocks of 8 outnumber the CUs, or when settings.persistent == 2 asks for it), -1 = none
+// which kernel runs this shape: 0 = the round-2 kernel, one wave per agent with 8 (3-D: 4) agents per workgroup; 1 = the lean
+// kernel, 16 agents per workgroup (2-D; taken when the blocks of 8 outnumber the CUs, or when settings.persistent == 2 asks for
+// it); 2 = the lean kernel's state diet with 8 agents per workgroup (3-D beyond 1024 agents; settings.persistent == 3: any
+// shape, measurements); -1 = none
 static int persist_variant_for(const scp_qp* qp) {
   // one workgroup per CU, all resident (grid-wide rendezvous); gpart / gcheck hold SCP_PERSIST_MAX_WG (+1) workgroups
   const int max_wg = std::min(qp->ctx->n_cu, SCP_PERSIST_MAX_WG);
   const int apb = persist_apb(qp->D);
-  const bool fits8 = (qp->N + apb - 1) / apb <= max_wg;
+  const bool fits_old = (qp->N + apb - 1) / apb <= max_wg;
   const bool fits16 = qp->D == 2 && (qp->N + 15) / 16 <= max_wg;
+  const bool fits8 = (qp->N + 7) / 8 <= max_wg;
   if (qp->st.persistent == 2 && fits16) return 1;
-  if (fits8) return 0;
+  if (qp->st.persistent == 3 && fits8) return 2;
+  if (fits_old) return 0;
+  if (qp->D == 3) return fits8 ? 2 : -1;
   return fits16 ? 1 : -1;
 }
+static int variant_apb(int variant, int D) { return variant == 1 ? 16 : (variant == 2 ? 8 : persist_apb(D)); }
 
 bool scp_qp_persist_eligible(const scp_qp* qp) {
   if (!qp->st.persistent || qp->st.cg_iters != 1 || qp->st.use_mfma != 1) return false;
@@ -723,7 +729,7 @@ bool scp_qp_persist_eligible(const scp_qp* qp) {
   const int variant = persist_variant_for(qp);
   // the lean kernel's one-double-per-row state presumes z = Pi(z + y / rho), which any ADMM update establishes and
   // scp_qp_reset (z = A x0, unprojected) does not: the first step of a QP is left to the three-launch pipeline
-  if (variant == 1 && qp->steps_since_reset == 0) return false;
+  if (variant >= 1 && qp->steps_since_reset == 0) return false;
   return variant >= 0;
 }
 
@@ -742,8 +748,8 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   const int64_t C = qp->C, nx = (int64_t)K * C;
   const int variant = persist_variant_for(qp);
   if (variant < 0) { *ran = 0; return SCP_OK; }
-  const bool lean = variant == 1;
-  const int apb = lean ? 16 : persist_apb(D);
+  const bool lean = variant >= 1;
+  const int apb = variant_apb(variant, D);
   const int nblk = (qp->N + apb - 1) / apb;
   *ran = 0;
   if (!qp->cg1_ready) {
@@ -756,8 +762,8 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   if (qp->persist_cap_nW == qp->nW) return SCP_OK;  // this working set overflowed before
   {
     const int nb = nblk + 1;  // (+1: the fault-injection hook below may announce one more workgroup)
-    const size_t fixed = lean ? scp_persist16_lds_bytes(K, 0, nb) : persist_lds_bytes(K, D, 0, nb);
-    const size_t per_entry = lean ? 12 * sizeof(double) + sizeof(int) : (size_t)(4 * D + 4) * sizeof(double) + 3 * sizeof(int);
+    const size_t fixed = lean ? scp_persist16_lds_bytes(K, 0, nb, D, apb) : persist_lds_bytes(K, D, 0, nb);
+    const size_t per_entry = (size_t)(4 * D + 4) * sizeof(double) + (lean ? 1 : 3) * sizeof(int);
     const size_t budget_lds = 160 * 1024 - (lean ? 2048 : 1024);  // minus the static __shared__ of the kernel (580 B / 1.2 KB)
     if (fixed + 64 * per_entry > budget_lds) return SCP_OK;
     qp->persist_cap = (int)((budget_lds - fixed) / per_entry / 64 * 64);
@@ -766,7 +772,7 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   // never complete -- the bounded spins must time out, every workgroup must leave without writing state back, and the
   // host must carry on with the three-launch pipeline
   const int nblk_expected = nblk + (qp->persist_fault > 0 ? 1 : 0);
-  const size_t lds = lean ? scp_persist16_lds_bytes(K, qp->persist_cap, nblk_expected)
+  const size_t lds = lean ? scp_persist16_lds_bytes(K, qp->persist_cap, nblk_expected, D, apb)
                           : persist_lds_bytes(K, D, qp->persist_cap, nblk_expected);
   if (lds > 160 * 1024) return SCP_OK;  // too many rows around one block of agents: three-launch pipeline
   const int budget = st.max_iter - it0;  // at most this many steps in this launch
@@ -844,7 +850,7 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   a.epoch0 = (unsigned)qp->persist_epoch;
   qp->persist_variant = variant;
   if (lean) {
-    int rc = scp_persist16_launch(ctx, a, nblk, lds);
+    int rc = scp_persist16_launch(ctx, a, nblk, lds, D, apb);
     if (rc) return rc;
   } else if (D == 2) {
     if (lds > 64 * 1024)

@@ -46,14 +46,17 @@ __device__ unsigned long long scp_persist16_clk[16];
 #define PSTAMP(slot) ((void)0)
 #endif
 
-constexpr int APB16 = 16;          // agents = waves per workgroup
-constexpr int NT16 = 64 * APB16;   // threads
-constexpr int NC16 = 2 * APB16;    // columns of a workgroup (2-D)
+// Instantiations: <2, 16> the lean kernel proper (2-D, 2048 < N <= 4096: four waves per SIMD, 128 registers);
+// <3, 8> 3-D with eight agents per workgroup (1024 < N <= 2048: the 4-agent 3-D kernel of scp_qp_persist.hip stops at 1024);
+// <2, 8> the same state diet at two waves per SIMD (settings.persistent = 3: measurements against the 8-agent kernel).
+constexpr int nct_of(int D, int APB) { return (D * APB + 15) / 16; }  // 16-column MFMA tiles of a workgroup
+constexpr int AB_STRIDE = 32;  // per-agent bound table: 8 groups of 4 doubles
 
 struct Lds16 {  // carve-up shared by the kernel and the host's size computation (doubles, then ints)
   int RSK, tK, nks;
   size_t rt, pt, ml, gp, ab, gchk, ent, n_dbl;
-  __host__ __device__ Lds16(int K, int cap, int nblk) {
+  __host__ __device__ Lds16(int K, int cap, int nblk, int D, int APB) {
+    const int NC16 = 16 * nct_of(D, APB), APB16 = APB;
     RSK = pad_col(K);
     tK = (K + 15) >> 4;
     nks = (K + 3) >> 2;
@@ -62,17 +65,20 @@ struct Lds16 {  // carve-up shared by the kernel and the host's size computation
     pt = o; o += (size_t)NC16 * RSK;
     ml = o; o += (size_t)tK * nks * 64;
     gp = o; o += (size_t)2 * nblk;
-    ab = o; o += (size_t)APB16 * 16;
+    ab = o; o += (size_t)APB16 * AB_STRIDE;
     // the nine-value all-gather of a termination check reuses the two tiles when they are large enough
     if ((size_t)2 * NC16 * RSK >= (size_t)NCHK * nblk) gchk = rt;
     else { gchk = o; o += (size_t)NCHK * nblk; }
-    ent = o; o += (size_t)cap * 12;
+    ent = o; o += (size_t)cap * (4 * D + 4);
     n_dbl = o;
   }
 };
 
-__global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
-  constexpr int D = 2;
+template <int D, int APB16>
+__global__ __launch_bounds__(64 * APB16) void cg1_persist16_kernel(PersistArgs A) {
+  constexpr int NT16 = 64 * APB16;             // threads: one wave per agent
+  constexpr int NCT = nct_of(D, APB16);        // column tiles of the MFMA phase
+  constexpr int NC16 = 16 * NCT;               // tile columns (D APB16 of them in use)
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ double red[NCHK][APB16];
   __shared__ double cert_s[3][APB16];  // per wave: |dy|, support value, |A^T dy| of the batch's last step (fixed rows)
@@ -89,13 +95,13 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
   const int K = A.K, N = A.N;
   const int64_t C = A.C;
   const int cap = A.ent_cap, nblk = A.nblk;
-  const Lds16 L(K, cap, nblk);
+  const Lds16 L(K, cap, nblk, D, APB16);
   const int RSK = L.RSK, tK = L.tK, nks = L.nks;
   double* Rt = lds + L.rt;            // [32][RSK] r, MFMA B operand
   double* Pt = lds + L.pt;            // [32][RSK] p, overwritten in place by the lane's S0 p cell (what the row loops read)
   double* Ml = lds + L.ml;            // [tK][nks][64] packed H_f^{-1}
   double* gp = lds + L.gp;            // [nblk][2] all-gathered line-search partials
-  double* ab = lds + L.ab;            // [16][16] per agent, x D: l_vel, u_vel, vf - v0, pos_min, pos_max, pf, -1e300, +1e300
+  double* ab = lds + L.ab;            // [APB][8 groups of 4] per agent, per axis: l_vel, u_vel, vf - v0, pos_min, pos_max, pf, -1e300, +1e300
   double* gck = lds + L.gchk;         // [nblk][9] all-gathered check results
   double* e_c = lds + L.ent;          // [cap][2] signed eta
   double* e_l = e_c + (size_t)cap * D;
@@ -184,17 +190,17 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
   // registers (the free position of the row's state, k + 1) and eight per-agent scalars in LDS, instead of being held in 16.
   if (threadIdx.x < APB16 * D) {
     const int al = threadIdx.x / D, d = threadIdx.x % D, ag = a0 + al;
-    double* o = ab + al * 16;
+    double* o = ab + al * AB_STRIDE;
     const bool there = ag < N;
     const double v0 = there ? A.states[((size_t)N + ag) * D + d] : 0.0;
     o[d] = A.vel_lo - v0;                                                        // l_vel, k < K - 1
-    o[2 + d] = A.vel_hi - v0;                                                    // u_vel
-    o[4 + d] = (there ? A.states[((size_t)3 * N + ag) * D + d] : 0.0) - v0;      // final velocity equality: vf - v0
-    o[6 + d] = A.pmin[d];
-    o[8 + d] = A.pmax[d];
-    o[10 + d] = there ? A.states[((size_t)2 * N + ag) * D + d] : 0.0;            // pf
-    o[12 + d] = -1e300;                                                          // rows beyond the horizon: no bound at all,
-    o[14 + d] = 1e300;                                                           // so that v = 0 stays 0 there
+    o[4 + d] = A.vel_hi - v0;                                                    // u_vel
+    o[8 + d] = (there ? A.states[((size_t)3 * N + ag) * D + d] : 0.0) - v0;      // final velocity equality: vf - v0
+    o[12 + d] = A.pmin[d];
+    o[16 + d] = A.pmax[d];
+    o[20 + d] = there ? A.states[((size_t)2 * N + ag) * D + d] : 0.0;            // pf
+    o[24 + d] = -1e300;                                                          // rows beyond the horizon: no bound at all,
+    o[28 + d] = 1e300;                                                           // so that v = 0 stays 0 there
   }
 #pragma unroll
   for (int d = 0; d < D; ++d) {
@@ -206,11 +212,11 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
   }
   // which table entries bound this lane's velocity / position rows: the inequalities, the final-state equalities
   // (k = K - 1: lower = upper), or nothing (beyond the horizon) -- an address per lane instead of selects per use
-  const double* const tb = ab + wave * 16;
-  const double* const b_vl = tb + (live ? (lastk ? 4 : 0) : 12);
-  const double* const b_vh = tb + (live ? (lastk ? 4 : 2) : 14);
-  const double* const b_pl = tb + (live ? (lastk ? 10 : 6) : 12);
-  const double* const b_ph = tb + (live ? (lastk ? 10 : 8) : 14);
+  const double* const tb = ab + wave * AB_STRIDE;
+  const double* const b_vl = tb + (live ? (lastk ? 8 : 0) : 24);
+  const double* const b_vh = tb + (live ? (lastk ? 8 : 4) : 28);
+  const double* const b_pl = tb + (live ? (lastk ? 20 : 12) : 24);
+  const double* const b_ph = tb + (live ? (lastk ? 20 : 16) : 28);
   auto bounds = [&](int d, double (&lo)[2], double (&hi)[2]) {
     lo[0] = b_vl[d];
     hi[0] = b_vh[d];
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
     __syncthreads();
     PSTAMP(1);
     // ---- p = H_f^{-1} r on the matrix cores: eight waves = 4 row tiles x 2 column tiles, operands streamed from LDS ----
-    if (wave < 8 && (wave & 3) < tK) {
+    if (wave < 4 * NCT && (wave & 3) < tK) {
       const int li = lane & 15, lk = lane >> 4;
       const int tile = wave & 3, ct = wave >> 2;
       const double* Mt = Ml + (size_t)tile * nks * 64 + lane;
@@ -343,7 +349,10 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
         u32x4 w[D];
         for (;;) {
           ld_cell<D>(pc, w);
-          if (pair_ok(w[0], tag) && pair_ok(w[1], tag)) break;
+          bool here = true;
+#pragma unroll
+          for (int d = 0; d < D; ++d) here = here && pair_ok(w[d], tag);
+          if (here) break;
           if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
                                        __hip_atomic_load(A.give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
             bad = true;
@@ -581,7 +590,10 @@ __global__ __launch_bounds__(NT16) void cg1_persist16_kernel(PersistArgs A) {
         u32x4 w[D];
         for (;;) {
           ld_cell<D>(pc, w);
-          if (pair_ok(w[0], ctag) && pair_ok(w[1], ctag)) break;
+          bool here = true;
+#pragma unroll
+          for (int d = 0; d < D; ++d) here = here && pair_ok(w[d], ctag);
+          if (here) break;
           if (++spins > SPIN_LIMIT || ((spins & 255u) == 0u &&
                                        __hip_atomic_load(A.give_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
             bad = true;
@@ -798,16 +810,24 @@ extern "C" int scp_debug_persist16_clocks(unsigned long long* out, int n) {
 }
 #endif
 
-size_t scp_persist16_lds_bytes(int K, int cap, int nblk) {
-  const Lds16 L(K, cap, nblk);
-  const size_t ints = (size_t)cap + (size_t)APB16 * K + 1;
+size_t scp_persist16_lds_bytes(int K, int cap, int nblk, int D, int apb) {
+  const Lds16 L(K, cap, nblk, D, apb);
+  const size_t ints = (size_t)cap + (size_t)apb * K + 1;
   return L.n_dbl * sizeof(double) + ((ints + 1) / 2 * 2) * sizeof(int);
 }
 
-int scp_persist16_launch(scp_ctx* ctx, const PersistArgs& a, int nblk, size_t lds) {
+template <int D, int APB>
+static int launch16(scp_ctx* ctx, const PersistArgs& a, int nblk, size_t lds) {
   if (lds > 64 * 1024)
-    SCP_HIP_CHECK(ctx, scp_raise_lds_limit(ctx->device, reinterpret_cast<const void*>(cg1_persist16_kernel), lds));
-  hipLaunchKernelGGL(cg1_persist16_kernel, dim3(nblk), dim3(NT16), lds, ctx->stream, a);
+    SCP_HIP_CHECK(ctx, scp_raise_lds_limit(ctx->device, reinterpret_cast<const void*>(cg1_persist16_kernel<D, APB>), lds));
+  hipLaunchKernelGGL((cg1_persist16_kernel<D, APB>), dim3(nblk), dim3(64 * APB), lds, ctx->stream, a);
   SCP_HIP_CHECK(ctx, hipGetLastError());
   return SCP_OK;
+}
+
+int scp_persist16_launch(scp_ctx* ctx, const PersistArgs& a, int nblk, size_t lds, int D, int apb) {
+  if (D == 2 && apb == 16) return launch16<2, 16>(ctx, a, nblk, lds);
+  if (D == 2 && apb == 8) return launch16<2, 8>(ctx, a, nblk, lds);
+  if (D == 3 && apb == 8) return launch16<3, 8>(ctx, a, nblk, lds);
+  return scp_fail(ctx, SCP_ERR_INVALID, "persistent kernel: no instantiation for D = %d with %d agents per workgroup", D, apb);
 }

@@ -92,5 +92,5 @@ __device__ inline double pair_value(const u32x4& w) { return __hiloint2double((i
 }  // namespace scp_persist
 
 // host side of the lean kernel (scp_qp_persist16.hip), called by scp_qp_cg1_persist
-size_t scp_persist16_lds_bytes(int K, int cap, int nblk);
-int scp_persist16_launch(scp_ctx* ctx, const scp_persist::PersistArgs& a, int nblk, size_t lds);
+size_t scp_persist16_lds_bytes(int K, int cap, int nblk, int D, int apb);
+int scp_persist16_launch(scp_ctx* ctx, const scp_persist::PersistArgs& a, int nblk, size_t lds, int D, int apb);

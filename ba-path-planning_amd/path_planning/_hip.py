@@ -22,7 +22,7 @@ STATUS_TEXT = {1: "solved", 2: "solved inaccurate", -2: "maximum iterations reac
 
 
 # enum scp_qp_pipeline: bit numbers of scp_qp_info.pipeline
-PIPELINES = ("qp0", "persistent", "persistent16", "three-launch", "three-launch-bigK", "fused", "generic")
+PIPELINES = ("qp0", "persistent", "persistent16", "three-launch", "three-launch-bigK", "fused", "generic", "persistent8-lean")
 
 
 def pipeline_names(mask):

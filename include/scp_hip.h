@@ -78,9 +78,10 @@ typedef struct scp_qp_settings {
   int32_t persistent;            /* 1: cg_iters == 1, K <= 64 and at most one block of 16/D agents per compute unit run
                                     all ADMM steps between two termination checks in ONE persistent launch (solver state
                                     on chip, two grid-wide exchanges per step) -- beyond that, 2-D problems of up to 16 agents
-                                    per compute unit (4096) run the lean 16-agent form of the kernel; 2: the lean form
-                                    whenever it fits (tests); 0: three launches per step.  Same arithmetic up to the
-                                    association of sums */
+                                    per compute unit (4096) run the lean 16-agent form of the kernel, 3-D problems of
+                                    1025..2048 agents its 8-agent 3-D form; 2: the lean 16-agent form whenever it fits, 3:
+                                    the lean 8-agent form whenever it fits (tests, measurements); 0: three launches per step.
+                                    Same arithmetic up to the association of sums */
 } scp_qp_settings;
 
 /* [host] result of scp_qp_solve */
@@ -109,7 +110,8 @@ typedef enum scp_qp_pipeline {
   SCP_PIPE_CG1 = 3,        /* single-step pipeline, three launches per ADMM step */
   SCP_PIPE_CG1_BIGK = 4,   /* the same with one workgroup per column (K > 120) */
   SCP_PIPE_FUSED = 5,      /* cg_iters > 1: fused column-block chains */
-  SCP_PIPE_GENERIC = 6     /* one product per launch */
+  SCP_PIPE_GENERIC = 6,    /* one product per launch */
+  SCP_PIPE_PERSIST8L = 7   /* the lean kernel's state diet with 8 agents per workgroup (3-D, 1024 < N <= 2048) */
 } scp_qp_pipeline;
 
 int scp_abi_version(void);

@@ -124,7 +124,7 @@ def test_every_qp_path_is_deterministic(ctx, cg, use_mfma):
         np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize("persistent", [1, 2])
+@pytest.mark.parametrize("persistent", [1, 2, 3])
 def test_in_kernel_rho_switch_equals_host_path(ctx, persistent):
     """Adaptive rho: the first solve of a QP object finds no cached blocks for the new rho values, so the persistent kernel
     returns and the host builds them (build_kkt + rows_value_kernel); a second solve of the SAME problem on the same object
@@ -147,7 +147,7 @@ def test_in_kernel_rho_switch_equals_host_path(ctx, persistent):
         qp.add_rows(torch.as_tensor(W, dtype=torch.int64, device=ctx.tdev), ctx.tensor(eta[W]), ctx.tensor(l_col[W]))
         info = qp.solve()
         yf, yc = qp.duals()
-        assert ("persistent16" if persistent == 2 else "persistent") in info["pipeline"]
+        assert {1: "persistent", 2: "persistent16", 3: "persistent8-lean"}[persistent] in info["pipeline"].split("+")
         runs.append((info["iter"], info["rho_updates"], info["status_val"], qp.solution().cpu().numpy(), yf.cpu().numpy(),
                      yc.cpu().numpy(), info["rho_switches_in_kernel"]))
     qp.close()
@@ -303,7 +303,7 @@ def test_persistent_kernel_equals_three_launch_pipeline(ctx, n, seed, dim):
     assert W.size > 0
     space = np.concatenate([prob.pos_min, prob.pos_max])
     states = {}
-    for persistent in (1, 0) + ((2,) if dim == 2 else ()):  # 2: the lean 16-agent kernel (2-D)
+    for persistent in (1, 0, 3) + ((2,) if dim == 2 else ()):  # 2: the lean 16-agent kernel (2-D), 3: its 8-agent form
         from path_planning import _hip
 
         st = _hip.default_settings(cg_iters=1, persistent=persistent, max_iter=12, check_termination=6, adaptive_rho=0,
@@ -314,7 +314,8 @@ def test_persistent_kernel_equals_three_launch_pipeline(ctx, n, seed, dim):
         qp.add_rows(torch.as_tensor(W, dtype=torch.int64, device=ctx.tdev), ctx.tensor(eta[W]), ctx.tensor(l_col[W]))
         info = qp.solve()
         assert info["iter"] == 12 and info["status_val"] == -2
-        assert info["pipeline"] == {1: "persistent", 0: "three-launch", 2: "persistent16+three-launch"}[persistent]
+        assert info["pipeline"] == {1: "persistent", 0: "three-launch", 2: "persistent16+three-launch",
+                                    3: "three-launch+persistent8-lean"}[persistent]
         states[persistent] = {k: qp.peek(k).cpu().numpy() for k in ("x", "zf", "yf", "fx", "qx", "zc", "yc", "gval")}
         states[persistent]["sol"] = qp.solution().cpu().numpy()
         qp.close()
@@ -357,7 +358,7 @@ def test_status_solved_inaccurate(ctx):
     assert hit is not None, "no iteration cap produced status 2"
 
 
-@pytest.mark.parametrize("persistent", [1, 2])
+@pytest.mark.parametrize("persistent", [1, 2, 3])
 def test_persistent_kernel_give_up_falls_back(ctx, persistent):
     """A persistent launch whose workgroups cannot all make progress (here: it is told to wait for a workgroup that does
     not exist) must time out in its bounded spins, leave WITHOUT writing state back, and the solve must carry on from the
@@ -396,7 +397,7 @@ def test_persistent_kernel_give_up_falls_back(ctx, persistent):
             qp.add_rows(torch.as_tensor(W, dtype=torch.int64, device=ctx.tdev), ctx.tensor(eta[W]), ctx.tensor(l_col[W]))
             assert qp.debug_set("persist_off", -1) == 0
             again = qp.solve()
-            assert again["pipeline"] == {1: "persistent", 2: "persistent16+three-launch"}[persistent]
+            assert again["pipeline"] == {1: "persistent", 2: "persistent16+three-launch", 3: "three-launch+persistent8-lean"}[persistent]
             assert again["persist_launches"] >= 1 and again["persist_gave_up"] == 0
             assert again["status_val"] == 1 and again["rho_switches_in_kernel"] <= again["rho_updates"]
             assert qp.debug_set("persist_gave_up_total", -1) == 1

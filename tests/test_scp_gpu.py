@@ -410,6 +410,30 @@ def test_carry_rho_follows_the_oracle():
     np.testing.assert_allclose(traj["positions"], base["positions"], rtol=0, atol=6e-2)
 
 
+def test_3d_beyond_1024_agents_on_the_persistent_path():
+    """3-D with more than 1024 agents: the 4-agent 3-D kernel runs out of compute units there and round 2 fell back to three
+    launches per ADMM step (45 us); the lean kernel's 8-agent 3-D form takes over up to 2048 agents.  One SCP iteration at
+    1100 x 50 x 3-D: the same ADMM count and accelerations (1e-9) as the three-launch pipeline from the same x0."""
+    from path_planning.scenarios.position_generator import generate_grid_swap
+    from path_planning.solvers.scp import SCP
+
+    n = 1100
+    p0, pf, space = generate_grid_swap(n, seed=5, dim=3)
+    out = {}
+    for persistent in (1, 0):
+        s = SCP(n, 10.0 + 1e-9, 0.2, 0.8, space, dim=3, verbose=False, qp_settings={"persistent": persistent})
+        s.set_initial_states(p0)
+        s.set_final_states(pf)
+        s._precompute_constraint_matrices()
+        acc0 = s._solve_initial_trajectory()
+        new, info = s.scp_iteration(acc0)
+        assert info["status_val"] == 1
+        out[persistent] = (new.cpu().numpy(), info)
+    assert "persistent8-lean" in out[1][1]["pipeline"].split("+") and out[0][1]["pipeline"] == "three-launch"
+    assert out[1][1]["iter"] == out[0][1]["iter"] and out[1][1]["working_rows"] == out[0][1]["working_rows"]
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=0, atol=1e-9)
+
+
 def test_lean_persistent_kernel_full_solves():
     """Complete solves with the lean 16-agent persistent kernel forced (persistent = 2) at sizes where the 8-agent kernel
     is the default: both follow the C oracle (SCP iteration count, ADMM counts to a check interval or two, waypoints to the
@@ -421,10 +445,10 @@ def test_lean_persistent_kernel_full_solves():
         prob = so.make_problem(n, 10.0, 0.2, 0.8, space, p0, pf)
         ref = co.scp_solve(prob, 15, qo.Settings(max_iter=10000))
         got = {}
-        for lean in (False, True):
-            s, traj = solve_gpu(n, 10.0, 0.2, 0.8, space, p0, pf, qp_settings={"persistent": 2 if lean else 1})
+        for lean in (False, True, 3):
+            s, traj = solve_gpu(n, 10.0, 0.2, 0.8, space, p0, pf, qp_settings={"persistent": {False: 1, True: 2, 3: 3}[lean]})
             assert s.last_info["converged"]
-            want = "persistent16" if lean else "persistent"
+            want = {False: "persistent", True: "persistent16", 3: "persistent8-lean"}[lean]
             pipes = [q["pipeline"] for q in s.last_info["iterations"]]
             assert all(want in q.split("+") for q in pipes), pipes
             assert s.last_info["n_iterations"] == ref["iterations"]
@@ -435,8 +459,9 @@ def test_lean_persistent_kernel_full_solves():
             got[lean] = (gi, traj["positions"])
         # lean against the 8-agent kernel directly: the association of sums differs, which the single-step path may amplify
         # (see TOL_DEFAULT); their state after 12 steps agrees to 1e-11 (test_persistent_kernel_equals_three_launch_pipeline)
-        assert all(abs(a - b) <= 50 for a, b in zip(got[False][0], got[True][0])), (got[False][0], got[True][0])
-        np.testing.assert_allclose(got[True][1], got[False][1], rtol=0, atol=TOL_DEFAULT)
+        for other in (True, 3):
+            assert all(abs(a - b) <= 50 for a, b in zip(got[False][0], got[other][0])), (got[False][0], got[other][0])
+            np.testing.assert_allclose(got[other][1], got[False][1], rtol=0, atol=TOL_DEFAULT)
 
 
 @pytest.mark.parametrize("N", [1024, 4096])

@@ -90,9 +90,9 @@ struct scp_qp {
   double space[6];                   // {min_0.., max_0..} of the latest scp_qp_set_problem
   double lim[6];                     // {vel, acc, jerk} x {min, max} of the latest scp_qp_set_problem (the lean persistent kernel
                                      // takes the jerk / acceleration bounds as scalars)
-  int64_t steps_since_reset;         // ADMM steps since scp_qp_reset: the lean persistent kernel keeps one double per fixed row
+  int64_t steps_since_reset;         // ADMM steps since scp_qp_reset: the lean persistent kernels keep one double per fixed row
                                      // (v = z~ + y / rho), which presumes z = Pi(v) -- true after any ADMM update, not for the
-                                     // unprojected z = A x0 of a reset: the first step of a QP runs on the three-launch pipeline
+                                     // unprojected z = A x0 of a reset: their first step of a QP takes z = v (y = 0 then)
   int persist_variant;               // of the latest persistent launch: 0 = 8 (4 in 3-D) agents per workgroup, 1 = lean, 16
   int persist_fault;                 // test hook: the next n persistent launches wait for a workgroup that does not exist
   bool persist_off;                  // a launch gave up (workgroups not co-resident): three-launch pipeline until the next

@@ -704,10 +704,11 @@ size_t persist_lds_bytes(int K, int D, int cap, int nblk) {
 }  // namespace
 
 // Can the persistent kernel run this QP?  (shape limits; the entry capacity is checked per working set)
-// which kernel runs this shape: 0 = the round-2 kernel, one wave per agent with 8 (3-D: 4) agents per workgroup; 1 = the lean
-// kernel, 16 agents per workgroup (2-D; taken when the blocks of 8 outnumber the CUs, or when settings.persistent == 2 asks for
-// it); 2 = the lean kernel's state diet with 8 agents per workgroup (3-D beyond 1024 agents; settings.persistent == 3: any
-// shape, measurements); -1 = none
+// which kernel runs this shape: 0 = the round-2 kernel, one wave per agent with 8 (3-D: 4) agents per workgroup and the full
+// z / y / F x state in registers; 1 = the lean kernel, 16 agents per workgroup (2-D, 2048 < N <= 4096); 2 = the lean kernel's
+// state diet with 8 agents per workgroup (2-D up to 2048 agents: 5-10 % faster per step than the round-2 kernel, measured --
+// profiles/r03_step_time_variants.txt; 3-D beyond 1024 agents); -1 = none.  settings.persistent: 1 = this choice, 2 / 3 / 4
+// force variant 1 / 2 / 0 where it fits.
 static int persist_variant_for(const scp_qp* qp) {
   // one workgroup per CU, all resident (grid-wide rendezvous); gpart / gcheck hold SCP_PERSIST_MAX_WG (+1) workgroups
   const int max_wg = std::min(qp->ctx->n_cu, SCP_PERSIST_MAX_WG);
@@ -717,20 +718,16 @@ static int persist_variant_for(const scp_qp* qp) {
   const bool fits8 = (qp->N + 7) / 8 <= max_wg;
   if (qp->st.persistent == 2 && fits16) return 1;
   if (qp->st.persistent == 3 && fits8) return 2;
-  if (fits_old) return 0;
-  if (qp->D == 3) return fits8 ? 2 : -1;
-  return fits16 ? 1 : -1;
+  if (qp->st.persistent == 4 && fits_old) return 0;
+  if (qp->D == 2) return fits8 ? 2 : (fits16 ? 1 : -1);
+  return fits_old ? 0 : (fits8 ? 2 : -1);  // 3-D: the 4-agent kernel is the faster one up to 1024 agents
 }
 static int variant_apb(int variant, int D) { return variant == 1 ? 16 : (variant == 2 ? 8 : persist_apb(D)); }
 
 bool scp_qp_persist_eligible(const scp_qp* qp) {
   if (!qp->st.persistent || qp->st.cg_iters != 1 || qp->st.use_mfma != 1) return false;
   if (qp->K > 64 || qp->nW <= 0 || qp->persist_off) return false;
-  const int variant = persist_variant_for(qp);
-  // the lean kernel's one-double-per-row state presumes z = Pi(z + y / rho), which any ADMM update establishes and
-  // scp_qp_reset (z = A x0, unprojected) does not: the first step of a QP is left to the three-launch pipeline
-  if (variant >= 1 && qp->steps_since_reset == 0) return false;
-  return variant >= 0;
+  return persist_variant_for(qp) >= 0;
 }
 
 // Run ADMM iterations from iteration count `it0` of the current solve in ONE launch, termination checks included, until
@@ -800,6 +797,7 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   a.acc_lo = qp->lim[2]; a.acc_hi = qp->lim[3]; a.jerk_lo = qp->lim[4]; a.jerk_hi = qp->lim[5];
   for (int dd = 0; dd < 3; ++dd) { a.pmin[dd] = qp->space[dd]; a.pmax[dd] = qp->space[3 + dd]; }
   a.states = d.states;
+  a.first_step = qp->steps_since_reset == 0 ? 1 : 0;  // (y = 0 and z = A x0 then: scp_qp_reset)
   {
     static const int spin_sleep = [] {  // developer knob (tools/batch_rate.sh experiments)
       const char* e = getenv("SCP_PERSIST_SPIN_SLEEP");

@@ -8,8 +8,8 @@
 //   * ONE double per fixed row instead of two: v = z~ + y / rho, the point the projection is applied to.  ADMM's update
 //     z' = Pi(v'), y' = rho (v' - Pi(v')) with v' = alpha F x~ + (1 - alpha) z + y / rho keeps z = Pi(v), y = rho (v - Pi(v)) as an
 //     invariant, so v' = v + alpha (F x~ - Pi(v)) and z, y are two clamps away wherever they are needed ("one
-//     state double per row").  The invariant holds after any ADMM update but not after scp_qp_reset (z = A x0 unprojected):
-//     the host runs the first step of a QP on the three-launch pipeline (scp_qp_solve).  Rounding-level differences only;
+//     state double per row").  The invariant holds after any ADMM update but not after scp_qp_reset (z = A x0 unprojected,
+//     y = 0): the first step of a QP takes z = v itself (PersistArgs::first_step).  Rounding-level differences only;
 //   * x and its first / second prefix sums c1 = cumsum(x), c2 = cumsum(c1) (exclusive) are carried, and F x, S0 x re-derived
 //     from them where the 8-agent kernel carries the F x slab (16 registers) and S0 x; F (x + a p) likewise comes from
 //     (c1 + a cumsum p, c2 + a cumsum^2 p), so F p is never formed.  Same quantities, sums associated differently;
@@ -254,6 +254,10 @@ __global__ __launch_bounds__(64 * APB16) void cg1_persist16_kernel(PersistArgs A
   for (int it = 0; it < nit; ++it, ++steps) {
     const unsigned tag = A.epoch0 + steps + 1u;
     const bool last = it == nit - 1;
+    // The one-double-per-row state presumes z = Pi(v).  Right after scp_qp_reset z = A x0 is NOT projected (and y = 0, so
+    // v = z): the first step of a QP therefore takes z = v instead of Pi(v) -- W' = rho (v - F x), v' = alpha F x~ +
+    // (1 - alpha) v, which is the standard update from (z, y) = (v, 0) -- and establishes the invariant for all later steps.
+    const bool first = A.first_step && steps == 0u;
     u64* gpart = A.gpart + (size_t)(tag & 1u) * nblk * 4;
     const double rv = lastk ? rho * A.rho_eq : rho;   // rho of this lane's velocity / position rows
     // ---- r = -2 x + F^T W' + S0^T G: reverse cumulative sums as suffix scans over the lanes ------------------------
@@ -273,8 +277,9 @@ __global__ __launch_bounds__(64 * APB16) void cg1_persist16_kernel(PersistArgs A
         double lo[2], hi[2];
         bounds(d, lo, hi);
         const double xn = lane_above(x[d]);
-        const double cj = fmin(fmax(v[d][0], jlo), jhi), ca = fmin(fmax(v[d][1], alo), ahi);
-        const double cv = fmin(fmax(v[d][2], lo[0]), hi[0]), cp = fmin(fmax(v[d][3], lo[1]), hi[1]);
+        double cj = fmin(fmax(v[d][0], jlo), jhi), ca = fmin(fmax(v[d][1], alo), ahi);
+        double cv = fmin(fmax(v[d][2], lo[0]), hi[0]), cp = fmin(fmax(v[d][3], lo[1]), hi[1]);
+        if (first) { cj = v[d][0]; ca = v[d][1]; cv = v[d][2]; cp = v[d][3]; }  // z of a reset is A x0 itself (y = 0, v = z)
         const double wj = jok ? rho * ((cj - (xn - x[d]) * ih) - (v[d][0] - cj)) : 0.0;
         const double wa = rho * ((ca - x[d]) - (v[d][1] - ca));
         const double wv = rv * ((cv - h * c1[d]) - (v[d][2] - cv));
@@ -472,8 +477,9 @@ __global__ __launch_bounds__(64 * APB16) void cg1_persist16_kernel(PersistArgs A
         double lo[2], hi[2];
         bounds(d, lo, hi);
         // v' = v + alpha (F x~ - Pi(v)); the new z, y are Pi(v'), rho (v' - Pi(v'))
-        const double cj = fmin(fmax(v[d][0], jlo), jhi), ca = fmin(fmax(v[d][1], alo), ahi);
-        const double cv = fmin(fmax(v[d][2], lo[0]), hi[0]), cp = fmin(fmax(v[d][3], lo[1]), hi[1]);
+        double cj = fmin(fmax(v[d][0], jlo), jhi), ca = fmin(fmax(v[d][1], alo), ahi);
+        double cv = fmin(fmax(v[d][2], lo[0]), hi[0]), cp = fmin(fmax(v[d][3], lo[1]), hi[1]);
+        if (first) { cj = v[d][0]; ca = v[d][1]; cv = v[d][2]; cp = v[d][3]; }
         const double nj = jok ? fma(alpha, (xtn - xt) * ih - cj, v[d][0]) : v[d][0];
         const double na = fma(alpha, xt - ca, v[d][1]);
         const double nv = fma(alpha, h * t1 - cv, v[d][2]);
@@ -706,8 +712,10 @@ __global__ __launch_bounds__(64 * APB16) void cg1_persist16_kernel(PersistArgs A
         const double nrs = A.tab[slot].rho;
         if (nrs > rho * A.rho_tol || nrs < rho / A.rho_tol) {
           // ---- switch rho in place (what the host does between two launches: build_kkt hit + rows_value_kernel) -------------
-          {  // y = rho (v - Pi(v)) must survive the switch: v <- Pi(v) + (v - Pi(v)) rho_old / rho_new
-            const double ratio = rho / nrs;
+          {  // y = rho (v - Pi(v)) must survive the switch.  EXACTLY the arithmetic of leaving (write-back: z = Pi(v), y = rho_old
+             // (v - Pi(v))) and re-entering with the new rho (load: v = z + y / rho_new), so that a solver object whose cache
+             // already holds the new rho's blocks (switch here) and a fresh one (exit, host builds the blocks, relaunch)
+             // produce the same bits -- records of pooled and one-at-a-time solves stay identical
 #pragma unroll
             for (int d = 0; d < D; ++d) {
               double lo[2], hi[2];
@@ -715,7 +723,11 @@ __global__ __launch_bounds__(64 * APB16) void cg1_persist16_kernel(PersistArgs A
               const double zc[4] = {fmin(fmax(v[d][0], jlo), jhi), fmin(fmax(v[d][1], alo), ahi),
                                     fmin(fmax(v[d][2], lo[0]), hi[0]), fmin(fmax(v[d][3], lo[1]), hi[1])};
 #pragma unroll
-              for (int t = 0; t < 4; ++t) v[d][t] = fma(v[d][t] - zc[t], ratio, zc[t]);
+              for (int t = 0; t < 4; ++t) {
+                const double rr_old = (t >= 2 && lastk) ? rho * A.rho_eq : rho, rr_new = (t >= 2 && lastk) ? nrs * A.rho_eq : nrs;
+                const double yv = rr_old * (v[d][t] - zc[t]);
+                v[d][t] = zc[t] + yv / rr_new;
+              }
             }
           }
           rho = nrs;

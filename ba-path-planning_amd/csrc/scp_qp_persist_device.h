@@ -20,6 +20,7 @@ struct PersistArgs {
   // bounds are made of (scp_qp_set_problem keeps a copy of the four state arrays: [4][N][D] = p0, v0, pf, vf)
   double jerk_lo, jerk_hi, acc_lo, acc_hi, vel_lo, vel_hi, pmin[3], pmax[3];
   const double* states;
+  int first_step;  // lean kernels: this launch starts with the first ADMM step after scp_qp_reset (z = A x0 unprojected, y = 0)
   int spin_sleep;  // naps (64 clocks each) between two polls of a granule that has not arrived (1; more when many persistent
                    // launches share the chip: their polls load the fabric the hand-offs travel on)
   const double* pMinv;

@@ -75,12 +75,12 @@ typedef struct scp_qp_settings {
                                     the same SCP iterates with 3.5 x fewer ADMM iterations than scale 1 */
   double eps_prim_inf;           /* 1e-4: OSQP's primal infeasibility tolerance; the certificate (delta-y test) is
                                     evaluated at every termination check; <= 0 disables it */
-  int32_t persistent;            /* 1: cg_iters == 1, K <= 64 and at most one block of 16/D agents per compute unit run
-                                    all ADMM steps between two termination checks in ONE persistent launch (solver state
-                                    on chip, two grid-wide exchanges per step) -- beyond that, 2-D problems of up to 16 agents
-                                    per compute unit (4096) run the lean 16-agent form of the kernel, 3-D problems of
-                                    1025..2048 agents its 8-agent 3-D form; 2: the lean 16-agent form whenever it fits, 3:
-                                    the lean 8-agent form whenever it fits (tests, measurements); 0: three launches per step.
+  int32_t persistent;            /* 1: with cg_iters == 1, K <= 64 and at most one block of agents per compute unit, all ADMM
+                                    steps between two termination checks run in ONE persistent launch (solver state on chip,
+                                    two grid-wide exchanges per step).  Which kernel: 2-D up to 2048 agents the lean kernel
+                                    with 8 agents per workgroup, up to 4096 with 16; 3-D up to 1024 agents the 4-agent kernel
+                                    of round 2, up to 2048 the lean one with 8.  2 / 3 / 4: force the lean 16-agent / lean
+                                    8-agent / round-2 kernel where it fits (tests, measurements); 0: three launches per step.
                                     Same arithmetic up to the association of sums */
 } scp_qp_settings;
 

@@ -75,8 +75,10 @@ def test_batch_cli_config5(tmp_path, capsys):
         n_it = r["scp_iterations"]
         assert len(r["iteration_time_sec"]) == len(r["rel_steps"]) == n_it and len(r["qp_iterations"]) == n_it + 1
         assert len(r["qp_residuals"]) == n_it + 1 and all(len(q) == 2 for q in r["qp_residuals"])
-        # which ADMM pipeline ran each QP (QP#0: column-local kernel; the joint QPs: the persistent kernel, no fallback)
-        assert r["qp_pipeline"][0] == "qp0" and all(p == "persistent" for p in r["qp_pipeline"][1:]), r["qp_pipeline"]
+        # which ADMM pipeline ran each QP (QP#0: column-local kernel; the joint QPs: the persistent kernel -- 2-D: the lean
+        # 8-agent form -- and no fallback)
+        assert r["qp_pipeline"][0] == "qp0", r["qp_pipeline"]
+        assert all(p == "persistent8-lean" for p in r["qp_pipeline"][1:]), r["qp_pipeline"]
         assert r["persist_gave_up"] == 0 and r["rho_switches_in_kernel"] >= 0
         assert sum(r["iteration_time_sec"]) <= r["time_sec"] and all(s in ("solved", "solved inaccurate") for s in r["qp_status"])
         if r["converged"]:

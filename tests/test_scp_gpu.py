@@ -446,7 +446,7 @@ def test_lean_persistent_kernel_full_solves():
         ref = co.scp_solve(prob, 15, qo.Settings(max_iter=10000))
         got = {}
         for lean in (False, True, 3):
-            s, traj = solve_gpu(n, 10.0, 0.2, 0.8, space, p0, pf, qp_settings={"persistent": {False: 1, True: 2, 3: 3}[lean]})
+            s, traj = solve_gpu(n, 10.0, 0.2, 0.8, space, p0, pf, qp_settings={"persistent": {False: 4, True: 2, 3: 3}[lean]})
             assert s.last_info["converged"]
             want = {False: "persistent", True: "persistent16", 3: "persistent8-lean"}[lean]
             pipes = [q["pipeline"] for q in s.last_info["iterations"]]

@@ -40,10 +40,11 @@ cp $(find $OUT/pmc_lds -name "*counter_collection.csv" | head -1) $OUT/qp_pmc_ld
 cd $R
 echo "== phase profiles of the persistent kernels, step times, box calibration"
 timeout -k 10 200 python3 tools/phase_profile.py 1024 > $OUT/phase_profile_n1024.txt 2>&1
+timeout -k 10 200 python3 tools/phase_profile.py 1024 4 > $OUT/phase_profile_round2_kernel_n1024.txt 2>&1
 head -12 $OUT/phase_profile_n1024.txt
 timeout -k 10 200 python3 tools/phase_profile.py 4096 > $OUT/phase_profile_lean_n4096.txt 2>&1
 head -12 $OUT/phase_profile_lean_n4096.txt
-timeout -k 10 200 python3 tools/step_time.py 128x2 1024x2 2048x2 2056x2 3000x2 4096x2 64x3 512x3 1024x3 > $OUT/step_time.txt 2>&1; cat $OUT/step_time.txt
+timeout -k 10 300 python3 tools/step_time.py 128x2 1024x2 1024x2x4 2048x2 2048x2x4 2056x2 3000x2 4096x2 64x3 512x3 1024x3 1100x3 2048x3 > $OUT/step_time.txt 2>&1; cat $OUT/step_time.txt
 timeout -k 10 60 tools/bin/membw > $OUT/membw.txt 2>&1
 SCP_HIP_LIB=$R/ba-path-planning_amd/lib/libscp_hip_prof.so timeout -k 10 200 python3 tools/pair_context.py --agents 1024 > $OUT/pair_context_clock_1024.txt 2>&1; cat $OUT/pair_context_clock_1024.txt
 echo "== 2-rank rehearsals on this one GPU (gloo, host-staged exchanges)"
@@ -59,6 +60,7 @@ timeout -k 10 200 python3 tools/full_solve_timing.py 64 256 1024 4096 > $OUT/ful
 timeout -k 10 200 python3 tools/ref_config_timing.py > $OUT/ref_config_timing.txt 2>&1
 timeout -k 10 300 python3 tools/soak.py 80 > $OUT/soak_80.txt 2>&1; tail -1 $OUT/soak_80.txt
 timeout -k 10 300 python3 tools/soak.py 80 --polish > $OUT/soak_80_polish.txt 2>&1; tail -1 $OUT/soak_80_polish.txt
+timeout -k 10 400 python3 tools/soak.py 24 --large > $OUT/soak_24_large.txt 2>&1; tail -1 $OUT/soak_24_large.txt
 # config 5's unit: 128-agent scenarios per second on this ONE GPU, processes x streams, steady state (--warmup 1), and the
 # cold figure (solver creation and kernel loading inside the clock) for one process
 TRIALS=256 bash tools/batch_rate.sh $OUT/batch128_rates.txt "1:1 1:4 2:4 4:4 4:5" > /dev/null 2>&1

@@ -24,11 +24,13 @@ COPIES = {
     "bench_n4096_1gpu.json": "bench_n4096_1gpu.json", "phase_profile_n1024.txt": "phase_profile_n1024.txt",
     "full_solve_timing.txt": "full_solve_timing.txt", "ref_config_timing.txt": "ref_config_timing.txt",
     "soak_80.txt": "soak_80_random_solves.txt", "soak_80_polish.txt": "soak_80_random_solves_polish.txt",
+    "soak_24_large.txt": "soak_24_large_solves.txt",
     "batch128_rates.txt": "batch128_rates.txt", "batch128_cold.txt": "batch128_cold.txt", "demo_k500.txt": "demo_k500.txt",
     "grid_sync_bench.txt": "grid_sync_bench.txt", "solve128.txt": "solve128.txt",
     "solve128_kernel_stats.csv": "solve128_kernel_stats.csv",
     "bench_n4096_1gpu_kernel_stats.csv": "bench_n4096_1gpu_kernel_stats.csv",
     "phase_profile_lean_n4096.txt": "phase_profile_lean_n4096.txt", "step_time.txt": "step_time.txt",
+    "phase_profile_round2_kernel_n1024.txt": "phase_profile_round2_kernel_n1024.txt",
     "bench_n1024_under_rocprof.json": "bench_n1024_under_rocprof.json",
     "rehearsal_2ranks_gloo_n1024.json": "rehearsal_2ranks_gloo_n1024.json",
     "rehearsal_2ranks_gloo_n4096.json": "rehearsal_2ranks_gloo_n4096.json",

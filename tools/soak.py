@@ -17,13 +17,20 @@ from path_planning.solvers.scp import SCP  # noqa: E402
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     polish = "--polish" in sys.argv  # one tight final QP: converged results must then pass the reference's R - 0.01 check
+    large = "--large" in sys.argv    # sizes 1000 .. 4096 (2-D) / 600 .. 2048 (3-D): every persistent-kernel variant and its edges
     floor = 0.8 - (0.01 if polish else 0.02)
     rng = np.random.default_rng(2026)
     bad = 0
     t0 = time.perf_counter()
     for case in range(n_cases):
         kind = rng.choice(["ref", "grid", "grid3d"])
-        if kind == "ref":
+        if large:
+            kind = rng.choice(["grid", "grid", "grid3d"])
+            dim = 3 if kind == "grid3d" else 2
+            N = int(rng.choice([2048, 2049, 4096, 1024, 1025]) if case < 5 and dim == 2 else
+                    rng.integers(1000, 4097) if dim == 2 else rng.integers(600, 2049))
+            p0, pf, space = generate_grid_swap(N, seed=int(rng.integers(1, 10**6)), dim=dim)
+        elif kind == "ref":
             N, dim = int(rng.integers(2, 21)), 2
             p0, pf = generate_positions(N, 0.8, seed=int(rng.integers(1, 10**6)))
             space = [0, 0, 20, 20]
@@ -31,7 +38,7 @@ def main():
             dim = 3 if kind == "grid3d" else 2
             N = int(rng.integers(2, 161))
             p0, pf, space = generate_grid_swap(N, seed=int(rng.integers(1, 10**6)), dim=dim)
-        T = float(rng.choice([6.0, 10.0, 13.0]))
+        T = 10.0 if large else float(rng.choice([6.0, 10.0, 13.0]))
         outs = []
         err = None
         for rep in range(2):
@@ -56,7 +63,8 @@ def main():
                                          "final_position_error", "final_velocity_error"))
             ok = ok and worst < 1e-5
         bad += 0 if ok else 1
-        print(f"case {case}: {kind} N={N} D={dim} T={T}: iterations={s.last_info['n_iterations']} converged={conv} "
+        pipes = sorted({p for q in s.last_info["iterations"] for p in q["pipeline"].split("+")})
+        print(f"case {case}: {kind} N={N} D={dim} T={T} {'+'.join(pipes)}: iterations={s.last_info['n_iterations']} converged={conv} "
               f"collision_free={rep_['collision_free']} min_dist={rep_['min_pair_distance']:.4f} finite={finite} "
               f"repeatable={same} {'OK' if ok else 'FAIL'}")
     print(f"{n_cases} cases, {bad} failures, {time.perf_counter() - t0:.1f} s")

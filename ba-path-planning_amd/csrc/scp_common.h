@@ -100,4 +100,5 @@ int scp_launch_from_time_major(scp_ctx* ctx, int N, int K, int D, const double* 
 // [3K-1,4K-1) pos, each row C = N*D wide.
 int scp_launch_bounds_time_major(scp_ctx* ctx, int N, int K, int D, double h, const double* limits_host,
                                  const double* space_host, const double* p0, const double* v0,
-                                 const double* pf, const double* vf, double* l_tm, double* u_tm);
+                                 const double* pf, const double* vf, double* l_tm, double* u_tm,
+                                 double* states_out /* [4][N][D] = p0, v0, pf, vf, or NULL */);

@@ -287,10 +287,16 @@ __global__ __launch_bounds__(256) void bounds_ref_order_kernel(BoundParams bp, i
 __global__ __launch_bounds__(256) void bounds_time_major_kernel(BoundParams bp, int N, int K, int D, double h,
                                                                  const double* p0, const double* v0,
                                                                  const double* pf, const double* vf,
-                                                                 double* __restrict__ l, double* __restrict__ u) {
+                                                                 double* __restrict__ l, double* __restrict__ u,
+                                                                 double* __restrict__ states_out) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t C = (int64_t)N * D;
   const int rows = 4 * K - 1;
+  if (states_out && t < 4 * C) {  // the QP's own copy of [p0 | v0 | pf | vf] (lean persistent kernels), no copy launches
+    const int which = (int)(t / C);
+    const int64_t c = t - which * C;
+    states_out[t] = which == 0 ? p0[c] : (which == 1 ? v0[c] : (which == 2 ? pf[c] : vf[c]));
+  }
   if (t >= C * rows) return;
   const int row = (int)(t / C);
   const int c = (int)(t % C);
@@ -338,12 +344,12 @@ extern "C" int scp_fixed_bounds(scp_ctx* ctx, int N, int K, int D, double h, con
 
 int scp_launch_bounds_time_major(scp_ctx* ctx, int N, int K, int D, double h, const double* limits,
                                  const double* space, const double* p0, const double* v0, const double* pf,
-                                 const double* vf, double* l_tm, double* u_tm) {
+                                 const double* vf, double* l_tm, double* u_tm, double* states_out) {
   BoundParams bp;
   fill_bound_params(bp, D, limits, space);
-  const int64_t m = (int64_t)N * D * (4 * K - 1);
+  const int64_t m = (int64_t)N * D * (4 * K - 1);  // (4K - 1 >= 4 rows: the grid covers the 4 N D states too)
   hipLaunchKernelGGL(bounds_time_major_kernel, dim3(scp_cdiv(m, 256)), dim3(256), 0, ctx->stream, bp, N, K, D, h,
-                     p0, v0, pf, vf, l_tm, u_tm);
+                     p0, v0, pf, vf, l_tm, u_tm, states_out);
   SCP_HIP_CHECK(ctx, hipGetLastError());
   return SCP_OK;
 }

@@ -944,17 +944,11 @@ extern "C" int scp_qp_set_problem(scp_qp* qp, const double* limits, const double
   if (!qp) return SCP_ERR_INVALID;
   SCP_REQUIRE(qp->ctx, limits && space && p0 && v0 && pf && vf, "qp_set_problem: null pointer");
   QP_CHECK(scp_launch_bounds_time_major(qp->ctx, qp->N, qp->K, qp->D, qp->h, limits, space, p0, v0, pf, vf, qp->d.lf,
-                                        qp->d.uf));
+                                        qp->d.uf, qp->d.states));
   memcpy(qp->lim, limits, sizeof(qp->lim));
   for (int d = 0; d < 3; ++d) {
     qp->space[d] = d < qp->D ? space[d] : 0.0;
     qp->space[3 + d] = d < qp->D ? space[qp->D + d] : 0.0;
-  }
-  {
-    const size_t nb = (size_t)qp->C * sizeof(double);
-    const double* src[4] = {p0, v0, pf, vf};
-    for (int i = 0; i < 4; ++i)
-      SCP_HIP_CHECK(qp->ctx, hipMemcpyAsync(qp->d.states + (size_t)i * qp->C, src[i], nb, hipMemcpyDeviceToDevice, qp->ctx->stream));
   }
   qp->problem_set = true;
   qp->reset_done = false;

@@ -355,16 +355,24 @@ class PairPass:
         self.last_linearize_ms = self.last_violations_ms = 0.0
         self.pos_prev = None  # linearisation point of the stored rows (kept for the recomputing violations pass)
 
+    def _alloc_planes(self):
+        # ONE allocation for the D eta planes and l: the linearisation kernel's three write streams run 5-6 % faster than
+        # into two allocations (tools/pair_align.py)
+        n_eta = max(self.D * self.stride, 2)
+        n_l = max(self.rows + (self.rows & 1), 2)
+        buf = self.ctx.empty(n_eta + n_l)
+        self._eta, self._l = buf[:n_eta], buf[n_eta:]
+
     @property
     def eta(self):
         if self._eta is None:
-            self._eta = self.ctx.empty(max(self.D * self.stride, 2))
+            self._alloc_planes()
         return self._eta
 
     @property
     def l(self):
         if self._l is None:
-            self._l = self.ctx.empty(max(self.rows + (self.rows & 1), 2))
+            self._alloc_planes()
         return self._l
 
     def _grow(self, need):

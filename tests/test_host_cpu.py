@@ -201,3 +201,42 @@ def test_graft_entry_build_runs_on_cpu():
     import __graft_entry__ as g
 
     g.build()
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """The ctypes mirrors of the [host] structs (scp_qp_settings, scp_qp_info, scp_solve_options, scp_qp_record,
+    scp_solve_result, scp_pair_stats) have the size and the field offsets gcc gives the C declarations of include/scp_hip.h."""
+    import ctypes
+    import subprocess
+
+    from path_planning import _hip
+
+    fields = {
+        "scp_qp_settings": (_hip.QpSettings, ["rho", "max_iter", "cg_iters", "rho_col_scale", "persistent"]),
+        "scp_qp_info": (_hip.QpInfo, ["status_val", "working_rows", "solve_ms", "pipeline", "rho_switches_in_kernel"]),
+        "scp_solve_options": (_hip.SolveOptions, ["max_iterations", "working_set_margin", "convergence_tolerance", "row_free",
+                                                  "carry_rho"]),
+        "scp_qp_record": (_hip.QpRecord, ["status_val", "pipeline", "working_rows", "added", "rel_step", "violations_ms",
+                                          "persist_launches", "reserved"]),
+        "scp_solve_result": (_hip.SolveResult, ["n_iterations", "first_violation", "time_sec"]),
+    }
+    src = ['#include <stddef.h>', '#include <stdio.h>', '#include "scp_hip.h"', "int main(void) {"]
+    for name, (_, fs) in fields.items():
+        src.append(f'  printf("{name} %zu", sizeof({name}));')
+        for f in fs:
+            src.append(f'  printf(" %zu", offsetof({name}, {f}));')
+        src.append('  printf("\\n");')
+    src.append('  printf("abi %d\\n", SCP_ABI_VERSION);')
+    src.append("  return 0; }")
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = {ln.split()[0]: [int(v) for v in ln.split()[1:]] for ln in out if ln.strip()}
+    for name, (cls, fs) in fields.items():
+        want = [ctypes.sizeof(cls)] + [getattr(cls, f).offset for f in fs]
+        assert got[name] == want, (name, got[name], want)
+    assert got["abi"] == [_hip.ABI_VERSION]
+    assert _hip.pipeline_names(0) == "none" and _hip.pipeline_names((1 << 1) | (1 << 3)) == "persistent+three-launch"
+    assert _hip.pipeline_names(1 << 7) == "persistent8-lean"

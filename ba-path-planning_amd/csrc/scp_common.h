@@ -27,6 +27,7 @@ struct scp_ctx {
   hipEvent_t ev0, ev1;
   hipEvent_t pair_ev0, pair_ev1;  // bracket the most recent pairwise kernel (scp_ctx_last_pair_ms)
   bool pair_timed;
+  bool pair_ran;
   double* tm_scratch;     // time-major copy of a trajectory array for the pairwise passes (grown on demand)
   size_t tm_bytes;
   uint32_t* cmp_map;      // scratch bitmap of the violations pass (self-cleaning), grown on demand
@@ -36,6 +37,7 @@ struct scp_ctx {
   scp_stats_mirror* h_mirror;  // mapped host memory and its device address
   scp_stats_mirror* d_mirror;
   unsigned long long mirror_seq;  // sequence number of the latest compaction launch
+  int timing;                     // HIP events around the pairwise kernels and the QP solves (scp_ctx_set_timing; default on)
   unsigned long long rel_seq;     // of the latest scp_rel_step (completion word: h_scratch[64]; partials: h_scratch[0..64))
 };
 

@@ -28,6 +28,7 @@ extern "C" int scp_ctx_create(int device, void* hip_stream, scp_ctx** out) {
   memset(ctx, 0, sizeof(*ctx));
   ctx->device = device;
   ctx->stream = (hipStream_t)hip_stream;
+  ctx->timing = 1;
   if (hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ctx->n_cu = 0;
   if (hipMalloc(&ctx->d_scratch, 72 * sizeof(double)) != hipSuccess ||
       hipMemset(ctx->d_scratch, 0, 72 * sizeof(double)) != hipSuccess ||  // ([64]: ticket counter of scp_rel_step)
@@ -42,6 +43,17 @@ extern "C" int scp_ctx_create(int device, void* hip_stream, scp_ctx** out) {
     return SCP_ERR_HIP;
   }
   *out = ctx;
+  return SCP_OK;
+}
+
+// HIP events around every pairwise kernel and every QP solve (two queue packets each) are what `linearize_ms`,
+// `violations_ms` and `solve_ms` are read from.  on = 0: none are recorded -- the pass times read 0, solve_ms becomes the
+// host's wall clock around the solve (the host waits for its result anyway).  For many concurrent solver threads
+// (compute-trajectories-batch), where every packet of a stream costs dispatch latency.
+extern "C" int scp_ctx_set_timing(scp_ctx* ctx, int on) {
+  if (!ctx) return SCP_ERR_INVALID;
+  ctx->timing = on ? 1 : 0;
+  if (!ctx->timing) ctx->pair_timed = false;
   return SCP_OK;
 }
 
@@ -943,7 +955,7 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
   const bool use_lds = lds_bytes <= 32 * 1024 && ((N * D) % 2 == 0) && !(a.ablate & 2);
   dim3 grid(scp_cdiv(nq + 1, PAIR_ROWS), K);
   dim3 block(PAIR_THREADS);
-  SCP_HIP_CHECK(ctx, hipEventRecord(ctx->pair_ev0, ctx->stream));
+  if (ctx->timing) SCP_HIP_CHECK(ctx, hipEventRecord(ctx->pair_ev0, ctx->stream));
 #define SCP_LAUNCH_PAIR(DD, LDS)                                                                        \
   hipLaunchKernelGGL((pair_pass_kernel<DD, MODE, LDS>), grid, block, (LDS) ? lds_bytes : 0, ctx->stream, a)
   if (D == 2) {
@@ -955,8 +967,9 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
   }
 #undef SCP_LAUNCH_PAIR
   SCP_HIP_CHECK(ctx, hipGetLastError());
-  SCP_HIP_CHECK(ctx, hipEventRecord(ctx->pair_ev1, ctx->stream));
-  ctx->pair_timed = true;
+  if (ctx->timing) SCP_HIP_CHECK(ctx, hipEventRecord(ctx->pair_ev1, ctx->stream));
+  ctx->pair_timed = ctx->timing != 0;
+  ctx->pair_ran = true;
   return SCP_OK;
 }
 
@@ -971,6 +984,10 @@ extern "C" int scp_debug_pair_clocks(unsigned long long* out, int n) {
 // Device time of the most recent pairwise kernel alone (HIP events on the ctx stream around that one launch).
 extern "C" int scp_ctx_last_pair_ms(scp_ctx* ctx, float* ms) {
   if (!ctx || !ms) return SCP_ERR_INVALID;
+  if (!ctx->pair_timed && ctx->pair_ran) {  // timing is off (scp_ctx_set_timing): no events were recorded
+    *ms = 0.f;
+    return SCP_OK;
+  }
   if (!ctx->pair_timed) return scp_fail(ctx, SCP_ERR_STATE, "no pairwise pass has run yet");
   SCP_HIP_CHECK(ctx, hipEventSynchronize(ctx->pair_ev1));
   SCP_HIP_CHECK(ctx, hipEventElapsedTime(ms, ctx->pair_ev0, ctx->pair_ev1));

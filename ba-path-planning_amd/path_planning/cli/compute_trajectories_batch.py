@@ -81,6 +81,7 @@ def run_single_trial(N, cfg, rng=None, seed=None, device=None, scenario=None, sa
                 verbose=cfg.get("verbose", False),
                 polish=cfg.get("polish", False),
                 carry_rho=cfg.get("carry_rho", False),
+                kernel_timing=cfg.get("kernel_timing", True),
                 qp_settings=cfg.get("qp_settings"),
             )
             if pool is not None:
@@ -196,10 +197,14 @@ def build_parser():
     p.add_argument("--warmup", type=int, default=0,
                    help="untimed solves per worker (stream) before the clock starts: the first solve of a worker builds its "
                         "solver object and loads the kernels (~0.1 s); with it the scenarios/s line is the steady-state rate")
-    p.add_argument("--qp-persistent", type=int, choices=[0, 1, 2], default=None,
-                   help="scp_qp_settings.persistent: 1 = persistent ADMM kernel with 8 agents per workgroup (default), 2 = its "
-                        "lean 16-agent form (half the compute units per solve: more solves side by side), 0 = three launches "
-                        "per ADMM step")
+    p.add_argument("--qp-persistent", type=int, choices=[0, 1, 2, 3, 4], default=None,
+                   help="scp_qp_settings.persistent: 1 = persistent ADMM kernel, variant chosen by size (default), 2 / 3 / 4 = "
+                        "force its lean 16-agent form (half the compute units per solve) / lean 8-agent form / round 2's "
+                        "kernel, 0 = three launches per ADMM step")
+    p.add_argument("--kernel-timing", type=int, choices=[0, 1], default=None,
+                   help="HIP events around the pairwise kernels and QP solves (the records' kernel times): default 1 for a single "
+                        "stream, 0 with --streams > 1 or several ranks (~25 queue packets fewer per solve; solve_ms is then "
+                        "host wall clock, linearize_ms / violations_ms read 0)")
     p.add_argument("--host-wait", type=int, choices=[0, 1, 2], default=None,
                    help="how worker threads wait for the GPU (scp_set_host_wait): 0 spin, 1 spin 20 us then nap (default with "
                         "--streams > 1 or several ranks), 2 nap at once (more workers than host cores)")
@@ -226,6 +231,8 @@ def main(argv=None):
     cfg["validate"] = bool(args.validate)
     cfg["polish"] = bool(args.polish)
     cfg["carry_rho"] = bool(args.carry_rho)
+    many = args.streams > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1
+    cfg["kernel_timing"] = bool(args.kernel_timing) if args.kernel_timing is not None else not many
     if args.qp_persistent is not None:
         cfg["qp_settings"] = {"persistent": int(args.qp_persistent)}
 

@@ -12,7 +12,7 @@ Differences to the reference that a caller can observe (INTEGRATION.md has the f
   * ``_add_collision_constraints`` returns the compact form (eta, l) of the constraint rows instead of a
     2.6e9-non-zero CSC matrix; ``C_jerk/C_acc/C_vel/C_pos`` are not materialised (they stay None);
   * new keyword-only arguments: ``dim`` (2 or 3), ``device``, ``qp_settings``, ``working_set_margin``,
-    ``feasibility_tol``, ``max_rounds``, ``refresh_feasibility``, ``polish``/``polish_eps``, ``native``, ``row_free``, ``carry_rho``,
+    ``feasibility_tol``, ``max_rounds``, ``refresh_feasibility``, ``polish``/``polish_eps``, ``native``, ``row_free``, ``carry_rho``, ``kernel_timing``,
     ``qp_row_capacity``, ``verbose``, ``rank``/``world_size``/``group`` (pair-range-sharded multi-GPU: the SCP iteration natively,
     split at its exchange points -- ``scp_iteration_sharded``).
 """
@@ -47,6 +47,7 @@ class SCP:
         native=True,
         row_free=True,
         carry_rho=False,
+        kernel_timing=True,
         qp_row_capacity=None,
         verbose=True,
         rank=0,
@@ -113,6 +114,11 @@ class SCP:
 
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
         self._ctx = _hip.Context(device)  # raises without a GPU / without libscp_hip.so
+        # False: no HIP events around the kernels (linearize_ms / violations_ms read 0, solve_ms is host wall clock): fewer queue
+        # packets per solve, for many concurrent solves on one GPU
+        self.kernel_timing = bool(kernel_timing)
+        if not self.kernel_timing:
+            self._ctx.set_timing(False)
         self._qp = None
         self._pairs = None
         self._dev = {}

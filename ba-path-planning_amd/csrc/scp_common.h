@@ -15,6 +15,8 @@ struct scp_stats_mirror {
   volatile unsigned long long seq;
 };
 
+constexpr int SCP_SMALL_MAX_WG = 2048;  // workgroups of a small-problem pairwise pass (the whole pass in one launch)
+
 struct scp_ctx {
   int device;
   int n_cu;  // compute units of the device (resident-workgroup limit of the persistent kernels)
@@ -28,6 +30,7 @@ struct scp_ctx {
   hipEvent_t pair_ev0, pair_ev1;  // bracket the most recent pairwise kernel (scp_ctx_last_pair_ms)
   bool pair_timed;
   bool pair_ran;
+  bool last_pass_small;  // the latest pairwise pass ran as ONE launch and published its stats in the host mirror (also a check pass)
   double* tm_scratch;     // time-major copy of a trajectory array for the pairwise passes (grown on demand)
   size_t tm_bytes;
   uint32_t* cmp_map;      // scratch bitmap of the violations pass (self-cleaning), grown on demand
@@ -37,7 +40,10 @@ struct scp_ctx {
   scp_stats_mirror* h_mirror;  // mapped host memory and its device address
   scp_stats_mirror* d_mirror;
   unsigned long long mirror_seq;  // sequence number of the latest compaction launch
-  int timing;                     // HIP events around the pairwise kernels and the QP solves (scp_ctx_set_timing; default on)
+  unsigned long long* wg_part;    // [SCP_SMALL_MAX_WG][2] per-workgroup partials of a small-problem pairwise pass
+  unsigned* d_ticket;             // its last-workgroup-done counter (zero between launches)
+  int timing;                     // HIP events around the pairwise kernels and the QP solves (scp_ctx_set_option; default on)
+  int small_pass;                 // one-launch pairwise passes for small problems (scp_ctx_set_option; default on)
   unsigned long long rel_seq;     // of the latest scp_rel_step (completion word: h_scratch[64]; partials: h_scratch[0..64))
 };
 
@@ -81,6 +87,14 @@ bool scp_wait_host_word(volatile unsigned long long* word, unsigned long long se
 // Stats of the latest scp_linearize_pairs / scp_collision_violations[_at] call of this ctx, from the host mirror: waits for
 // that pass's last kernel only (no stream drain, no copy launch).
 int scp_ctx_wait_stats(scp_ctx* ctx, scp_pair_stats* out);
+
+// scp_qp_get_solution + scp_kinematics + scp_collision_violations_at of a small problem in one launch (scp_kernels.hip)
+int scp_violations_from_solution(scp_ctx* ctx, int N, int K, int D, double R, double h, int64_t q_begin, int64_t q_end,
+                                 const double* pos_prev, const double* x_tm, const double* p0, const double* v0, double* x_out,
+                                 double* pos_out, double feas_tol, int64_t* new_rows, int64_t new_cap, uint32_t* sel_bitmap,
+                                 scp_pair_stats* stats, bool* fused);
+// the QP's current iterate in its own layout ([K][N D], device pointer)
+const double* scp_qp_solution_tm(const scp_qp* qp);
 
 // scp_gather_rows + scp_qp_add_rows in one launch: eta / l_col are the outputs of scp_linearize_pairs over [q_begin, q_end)
 int scp_qp_add_rows_from_pass(scp_qp* qp, int64_t n, const int64_t* rows, const double* eta, const double* l_col,

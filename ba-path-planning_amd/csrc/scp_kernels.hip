@@ -29,6 +29,7 @@ extern "C" int scp_ctx_create(int device, void* hip_stream, scp_ctx** out) {
   ctx->device = device;
   ctx->stream = (hipStream_t)hip_stream;
   ctx->timing = 1;
+  ctx->small_pass = getenv("SCP_NO_SMALL_PASS") ? 0 : 1;  // (developer switch; scp_ctx_set_option at run time)
   if (hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ctx->n_cu = 0;
   if (hipMalloc(&ctx->d_scratch, 72 * sizeof(double)) != hipSuccess ||
       hipMemset(ctx->d_scratch, 0, 72 * sizeof(double)) != hipSuccess ||  // ([64]: ticket counter of scp_rel_step)
@@ -38,7 +39,9 @@ extern "C" int scp_ctx_create(int device, void* hip_stream, scp_ctx** out) {
       hipHostMalloc(&ctx->h_mirror, sizeof(scp_stats_mirror)) != hipSuccess ||
       hipHostGetDevicePointer((void**)&ctx->d_mirror, ctx->h_mirror, 0) != hipSuccess ||
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-      hipEventCreate(&ctx->pair_ev0) != hipSuccess || hipEventCreate(&ctx->pair_ev1) != hipSuccess) {
+      hipEventCreate(&ctx->pair_ev0) != hipSuccess || hipEventCreate(&ctx->pair_ev1) != hipSuccess ||
+      hipMalloc(&ctx->wg_part, 2 * SCP_SMALL_MAX_WG * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc(&ctx->d_ticket, 64) != hipSuccess || hipMemset(ctx->d_ticket, 0, 64) != hipSuccess) {
     delete ctx;
     return SCP_ERR_HIP;
   }
@@ -46,15 +49,23 @@ extern "C" int scp_ctx_create(int device, void* hip_stream, scp_ctx** out) {
   return SCP_OK;
 }
 
-// HIP events around every pairwise kernel and every QP solve (two queue packets each) are what `linearize_ms`,
-// `violations_ms` and `solve_ms` are read from.  on = 0: none are recorded -- the pass times read 0, solve_ms becomes the
-// host's wall clock around the solve (the host waits for its result anyway).  For many concurrent solver threads
-// (compute-trajectories-batch), where every packet of a stream costs dispatch latency.
-extern "C" int scp_ctx_set_timing(scp_ctx* ctx, int on) {
-  if (!ctx) return SCP_ERR_INVALID;
-  ctx->timing = on ? 1 : 0;
-  if (!ctx->timing) ctx->pair_timed = false;
-  return SCP_OK;
+// Per-context switches (include/scp_hip.h).  "kernel_timing": HIP events around every pairwise kernel and every QP solve
+// (two queue packets each) are what `linearize_ms`, `violations_ms` and `solve_ms` are read from; 0: none are recorded --
+// the pass times read 0, solve_ms becomes the host's wall clock around the solve (the host waits for its result anyway).
+// "single_launch_passes": the one-launch form of the pairwise passes of small problems (pair_pass_kernel<.., SMALL>); 0:
+// prep kernel + pass + compaction as for large problems (same results; tests compare the two).
+extern "C" int scp_ctx_set_option(scp_ctx* ctx, const char* key, int value) {
+  if (!ctx || !key) return SCP_ERR_INVALID;
+  if (strcmp(key, "kernel_timing") == 0) {
+    ctx->timing = value ? 1 : 0;
+    if (!ctx->timing) ctx->pair_timed = false;
+    return SCP_OK;
+  }
+  if (strcmp(key, "single_launch_passes") == 0) {
+    ctx->small_pass = value ? 1 : 0;
+    return SCP_OK;
+  }
+  return scp_fail(ctx, SCP_ERR_INVALID, "ctx_set_option: unknown key '%s'", key);
 }
 
 extern "C" void scp_ctx_destroy(scp_ctx* ctx) {
@@ -62,6 +73,8 @@ extern "C" void scp_ctx_destroy(scp_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->d_scratch);
+  if (ctx->wg_part) (void)hipFree(ctx->wg_part);
+  if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
   if (ctx->cmp_map) (void)hipFree(ctx->cmp_map);
   if (ctx->cmp_tot) (void)hipFree(ctx->cmp_tot);
   if (ctx->tm_scratch) (void)hipFree(ctx->tm_scratch);
@@ -186,32 +199,41 @@ int scp_launch_from_time_major(scp_ctx* ctx, int N, int K, int D, const double* 
 // reference's order with separately rounded multiply and add (no FMA) so the result is bitwise the
 // reference's.
 // ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void kinematics_kernel(int N, int K, int D, double h,
-                                                          const double* __restrict__ acc,
-                                                          const double* __restrict__ p0,
-                                                          const double* __restrict__ v0, double* __restrict__ pos,
-                                                          double* __restrict__ vel) {
+// position (and velocity) of one coordinate at step k from its acceleration samples a[0], a[stride], ...: ONE definition for
+// the kinematics kernel and for the small-problem violations pass that derives its positions from the QP's time-major
+// solution itself (pair_pass_kernel<.., SMALL>), so that both produce the same bits
+__device__ inline void kin_point(const double* __restrict__ a, int64_t stride, int k, double h, double pi, double vi,
+                                 double& p_out, double& v_out) {
 #pragma clang fp contract(off)  // every product below is rounded before it is added, as numpy does
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (int64_t)N * K * D) return;
-  const int d = (int)(t % D);
-  const int k = (int)((t / D) % K);
-  const int i = (int)(t / ((int64_t)D * K));
-  const double pi = p0[i * D + d], vi = v0[i * D + d];
   double v = vi;
   const double hk = h * (double)k;
   const double hkv = hk * vi;
   double p = pi + hkv;  // p0 + (h*k)*v0   scp.py:393
   const double hh = h * h;
-  const double* a = acc + (int64_t)i * K * D + d;
   for (int j = 0; j < k; ++j) {
-    const double aj = a[(int64_t)j * D];
+    const double aj = a[(int64_t)j * stride];
     const double hv = h * aj;
     v = v + hv;  // scp.py:390
     const double w = hh * ((double)(k - j) - 0.5);
     const double wa = w * aj;
     p = p + wa;  // scp.py:395
   }
+  p_out = p;
+  v_out = v;
+}
+
+__global__ __launch_bounds__(256) void kinematics_kernel(int N, int K, int D, double h,
+                                                          const double* __restrict__ acc,
+                                                          const double* __restrict__ p0,
+                                                          const double* __restrict__ v0, double* __restrict__ pos,
+                                                          double* __restrict__ vel) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)N * K * D) return;
+  const int d = (int)(t % D);
+  const int k = (int)((t / D) % K);
+  const int i = (int)(t / ((int64_t)D * K));
+  double p, v;
+  kin_point(acc + (int64_t)i * K * D + d, D, k, h, p0[i * D + d], v0[i * D + d], p, v);
   pos[t] = p;
   if (vel) vel[t] = v;
 }
@@ -453,6 +475,7 @@ struct PairUnroll {
   static constexpr int value = (USE_LDS && MODE != 2 /* MODE_VIOLATIONS: streaming reads, 4 in flight */) ? 2 : 4;
 };
 constexpr int PAIR_ROWS = PAIR_THREADS * PAIR_STEPS * 2;   // rows (= pairs at one k) per workgroup
+constexpr int64_t CMP1_MAX_WORDS = 64 * 1024;             // bitmap words (2 M rows) one workgroup compacts (compact_small_body)
 
 enum PairMode { MODE_LINEARIZE = 0, MODE_CHECK = 1, MODE_VIOLATIONS = 2, MODE_VIOL_RECOMPUTE = 3, MODE_SELECT = 4 };
 // MODE_SELECT: the linearisation pass WITHOUT its row stream (scp_select_pairs): the same distances, the same selection test
@@ -478,6 +501,22 @@ struct PairArgs {
   uint32_t* mark;          // bits set by this pass: the bitmap itself (linearize) or a scratch map (violations)
   scp_pair_stats* stats;
   int ablate;            // developer switch (profiling build, env SCP_PAIR_ABLATE): 1 = skip the streaming stores, 2 = force no-LDS
+  // ---- small problems (SMALL instantiations: the whole pass in ONE launch) --------------------------------------------
+  const double* pos_a;   // [N][K][D] the pass's positions (select / check) or the linearisation point (violations)
+  const double* pos_b;   // [N][K][D] new positions (violations), or NULL: derived from x_tm
+  const double* x_tm;    // [K][N D] the QP's solution (time-major); p0, v0, h: its kinematics
+  const double *p0, *v0;
+  double* x_out;         // [N][K][D] copy of x_tm, and
+  double* pos_out;       // [N][K][D] its positions (written by the first workgroup of every time step)
+  unsigned long long* wg_part;  // [workgroups][2]: per-workgroup (min distance | max violation, first violation)
+  unsigned* ticket;      // last-workgroup-done counter (self-resetting)
+  int64_t* rows;         // tail: the sorted list of the marked rows, capacity `cap`
+  int64_t cap;
+  uint32_t* merge_into;  // tail: the working-set bitmap the marks are merged into (violations) / that they replace (select)
+  int overwrite;
+  int64_t words;
+  scp_stats_mirror* mirror;
+  unsigned long long seq;
 };
 
 // c_i[k] = p0 + (k h) v0: the free motion a row's lower bound is measured from (scp.py:543-549).  ONE definition for the
@@ -605,7 +644,18 @@ constexpr int SCP_PAIR_CLK_WGS = 4096;
 __device__ unsigned long long scp_pair_clk[2 * SCP_PAIR_CLK_WGS];
 #endif
 
-template <int D, int MODE, bool USE_LDS>
+template <int THREADS, bool COHERENT>
+__device__ inline int compact_small_body(uint32_t* __restrict__ map, int64_t words, int64_t nq, int64_t q_begin,
+                                         int64_t pairs, int64_t* __restrict__ rows, int64_t cap,
+                                         uint32_t* __restrict__ merge_into, bool overwrite);
+
+// SMALL (problems whose bitmap one workgroup compacts: <= 2 M rows, e.g. 128 agents x 50 steps): the pass is ONE launch.
+// Every workgroup stages its time step straight from the [N][K][D] arrays (no prep kernel) -- the violations pass can even
+// derive the new positions from the QP's time-major solution (kin_point: no from_time_major, no kinematics launch) --,
+// leaves its reduction as a per-workgroup partial (no atomics on the stats, nothing to initialise), and the LAST workgroup
+// to finish (a ticket) reduces the partials, compacts the bitmap into the sorted row list (compact_small_body) and
+// publishes the stats in the host mirror.  Same values, same list: the order of the partials does not matter for min / max.
+template <int D, int MODE, bool USE_LDS, bool SMALL = false>
 __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
   constexpr int PAIR_UNROLL = PairUnroll<USE_LDS, MODE>::value;
 #ifdef SCP_PHASE_PROFILE
@@ -624,7 +674,34 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
 
   const double* P = NEED_P ? a.P_tm + (int64_t)k * N * D : nullptr;
   const double* Q = NEED_Q ? a.Q_tm + (int64_t)k * N * D : nullptr;
-  if (USE_LDS) {
+  if (SMALL) {
+    double* sP = lds;
+    double* sQ = lds + (NEED_P ? (int64_t)N * D : 0);
+    const int C = N * D;
+    for (int c = threadIdx.x; c < C; c += PAIR_THREADS) {
+      const int i = c / D, d = c - i * D;
+      const int64_t g = ((int64_t)i * a.K + k) * D + d;
+      const double pa = a.pos_a[g];
+      if (NEED_P) sP[c] = pa;
+      if (MODE == MODE_VIOL_RECOMPUTE) {
+        double pn;
+        if (a.x_tm) {
+          double vn;
+          kin_point(a.x_tm + c, C, k, a.h, a.p0[c], a.v0[c], pn, vn);
+          if (blockIdx.x == 0) {
+            a.pos_out[g] = pn;
+            a.x_out[g] = a.x_tm[(int64_t)k * C + c];
+          }
+        } else {
+          pn = a.pos_b[g];
+        }
+        sQ[c] = pn - pa;  // dP = P_new - P_prev (pair_prep_delta_kernel)
+      }
+    }
+    __syncthreads();
+    P = sP;
+    Q = sQ;
+  } else if (USE_LDS) {
     double* sP = lds;
     double* sQ = lds + (NEED_P ? (int64_t)N * D : 0);
     const int n2 = (N * D) >> 1;  // slices are 16-byte aligned: N*D*8 bytes from an aligned base, even count or tail
@@ -854,6 +931,77 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
     red_u[threadIdx.x >> 6] = my_first;
   }
   __syncthreads();
+  if (SMALL) {
+    __shared__ int last_sh;
+    const unsigned n_wg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0) {
+      double m = red_d[0];
+      unsigned long long f = red_u[0];
+#pragma unroll
+      for (int w = 1; w < PAIR_THREADS / 64; ++w) {
+        m = VIOL ? fmax(m, red_d[w]) : fmin(m, red_d[w]);
+        f = red_u[w] < f ? red_u[w] : f;
+      }
+      __hip_atomic_store(a.wg_part + 2 * wg, (unsigned long long)__double_as_longlong(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.wg_part + 2 * wg + 1, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();  // this thread's marks (and the partial) are visible device-wide ...
+    __syncthreads();
+    if (threadIdx.x == 0) last_sh = atomicAdd(a.ticket, 1u) == n_wg - 1 ? 1 : 0;  // ... before the ticket is taken
+    __syncthreads();
+    if (!last_sh) return;
+    __threadfence();
+    // ---- tail: the last workgroup alone ----
+    double m = VIOL ? -INF : INF;
+    unsigned long long f = 0xFFFFFFFFFFFFFFFFULL;
+    for (unsigned w = threadIdx.x; w < n_wg; w += PAIR_THREADS) {
+      const double pm = __longlong_as_double((long long)__hip_atomic_load(a.wg_part + 2 * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const unsigned long long pf = __hip_atomic_load(a.wg_part + 2 * w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      m = VIOL ? fmax(m, pm) : fmin(m, pm);
+      f = pf < f ? pf : f;
+    }
+    m = VIOL ? wave_max(m) : wave_min(m);
+    f = wave_min_u64(f);
+    __syncthreads();  // (red_d / red_u of this workgroup's own reduction have been read)
+    if ((threadIdx.x & 63) == 63) {
+      red_d[threadIdx.x >> 6] = m;
+      red_u[threadIdx.x >> 6] = f;
+    }
+    int total = 0;
+    if (MODE != MODE_CHECK)
+      total = compact_small_body<PAIR_THREADS, true>(a.mark, a.words, nq, a.q_begin, a.pairs, a.rows, a.cap, a.merge_into,
+                                                     a.overwrite != 0);
+    else
+      __syncthreads();
+    if (threadIdx.x == 0) {
+      m = red_d[0];
+      f = red_u[0];
+#pragma unroll
+      for (int w = 1; w < PAIR_THREADS / 64; ++w) {
+        m = VIOL ? fmax(m, red_d[w]) : fmin(m, red_d[w]);
+        f = red_u[w] < f ? red_u[w] : f;
+      }
+      scp_pair_stats st;
+      st.min_dist = VIOL ? INF : m;
+      st.first_violation = f;
+      st.n_selected = (unsigned long long)total;
+      st.max_violation = VIOL ? m : -INF;
+      *a.stats = st;
+      *a.ticket = 0u;  // (the next launch on this stream starts after this kernel has ended)
+      if (a.mirror) {
+        __hip_atomic_store((unsigned long long*)&a.mirror->stats.min_dist, (unsigned long long)__double_as_longlong(st.min_dist),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((unsigned long long*)&a.mirror->stats.first_violation, st.first_violation, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((unsigned long long*)&a.mirror->stats.n_selected, st.n_selected, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((unsigned long long*)&a.mirror->stats.max_violation,
+                           (unsigned long long)__double_as_longlong(st.max_violation), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((unsigned long long*)&a.mirror->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    return;
+  }
   if (threadIdx.x == 0) {
     if (!VIOL) {
       double m = red_d[0];
@@ -922,12 +1070,63 @@ __global__ __launch_bounds__(256) void pair_prep_delta_kernel(int N, int K, int 
   dP_tm[t] = pos_new[g] - pp;
 }
 
+// What follows a pass: its marks become the sorted row list `rows` and are merged into (violations) / replace (select) the
+// working-set bitmap `merge_into`.  Small problems run it as the tail of the pass kernel itself (*done = true), the others
+// in launch_compaction afterwards.
+struct PassTail {
+  int64_t* rows;
+  int64_t cap;
+  uint32_t* merge_into;
+  bool overwrite;
+  int64_t words;
+  bool done;
+};
+
+// a pass over nq pairs x K steps that runs as ONE launch (pair_pass_kernel<.., SMALL>): its bitmap fits the one-workgroup
+// compaction, its time-step slices (n_slices of them) the LDS budget of the pass, its partials the ctx scratch
+static bool small_pass_ok(const scp_ctx* ctx, int N, int K, int D, int64_t nq, int n_slices) {
+  if (!ctx->small_pass || nq <= 0) return false;
+  const int64_t words = (K * nq + 31) / 32;
+  const int64_t n_wg = (int64_t)scp_cdiv(nq + 1, PAIR_ROWS) * K;
+  return words <= CMP1_MAX_WORDS && (size_t)n_slices * N * D * sizeof(double) <= 32 * 1024 && n_wg <= SCP_SMALL_MAX_WG;
+}
+
 // MODE_VIOL_RECOMPUTE: pos_ref_layout = the linearisation point, p0 = the new positions (v0 unused)
 template <int MODE>
 static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_layout, const double* p0,
-                            const double* v0, uint32_t* clear_map = nullptr, int64_t clear_words = 0) {
+                            const double* v0, uint32_t* clear_map = nullptr, int64_t clear_words = 0,
+                            PassTail* tail = nullptr) {
   const int N = a.N, K = a.K, D = a.D;
   const int64_t nq = a.q_end - a.q_begin;
+  if (tail) tail->done = false;
+  if constexpr (MODE == MODE_SELECT || MODE == MODE_VIOL_RECOMPUTE || MODE == MODE_CHECK)
+  if (tail) {
+    const size_t lds_small = (size_t)(MODE == MODE_VIOL_RECOMPUTE ? 2 : 1) * N * D * sizeof(double);
+    if (small_pass_ok(ctx, N, K, D, nq, MODE == MODE_VIOL_RECOMPUTE ? 2 : 1)) {
+      a.pos_a = pos_ref_layout;
+      if (MODE == MODE_SELECT) a.mark = ctx->cmp_map;  // (marks go to the self-cleaning scratch map; the tail turns them into the bitmap)
+      if (MODE == MODE_VIOL_RECOMPUTE && !a.x_tm) a.pos_b = p0;
+      a.wg_part = ctx->wg_part;
+      a.ticket = ctx->d_ticket;
+      a.rows = tail->rows; a.cap = tail->cap; a.merge_into = tail->merge_into; a.overwrite = tail->overwrite ? 1 : 0;
+      a.words = tail->words;
+      a.mirror = ctx->d_mirror;
+      a.seq = ++ctx->mirror_seq;
+      a.ablate = 0;
+      dim3 grid(scp_cdiv(nq + 1, PAIR_ROWS), K);
+      if (ctx->timing) SCP_HIP_CHECK(ctx, hipEventRecord(ctx->pair_ev0, ctx->stream));
+      if (D == 2) hipLaunchKernelGGL((pair_pass_kernel<2, MODE, true, true>), grid, dim3(PAIR_THREADS), lds_small, ctx->stream, a);
+      else hipLaunchKernelGGL((pair_pass_kernel<3, MODE, true, true>), grid, dim3(PAIR_THREADS), lds_small, ctx->stream, a);
+      SCP_HIP_CHECK(ctx, hipGetLastError());
+      if (ctx->timing) SCP_HIP_CHECK(ctx, hipEventRecord(ctx->pair_ev1, ctx->stream));
+      ctx->pair_timed = ctx->timing != 0;
+      ctx->pair_ran = true;
+      tail->done = true;
+      ctx->last_pass_small = true;
+      return SCP_OK;
+    }
+  }
+  ctx->last_pass_small = false;
   const size_t slice = ((size_t)N * K * D + 1) & ~(size_t)1;  // keep the second array 16-byte aligned
   int rc = ensure_tm(ctx, 2 * slice * sizeof(double));
   if (rc) return rc;
@@ -1125,42 +1324,47 @@ __global__ __launch_bounds__(CMP_THREADS) void compact_write_kernel(uint32_t* __
 // stats mirror in ONE workgroup -- the three-launch version costs more in launch boundaries than in work there.
 constexpr int CMP1_THREADS = 1024;
 constexpr int CMP1_WORDS = CMP1_THREADS * CMP_WPT;
-constexpr int64_t CMP1_MAX_WORDS = 64 * 1024;
 
-__global__ __launch_bounds__(CMP1_THREADS) void compact_small_kernel(uint32_t* __restrict__ map, int64_t words, int64_t nq,
-                                                                      int64_t q_begin, int64_t pairs,
-                                                                      int64_t* __restrict__ rows, int64_t cap,
-                                                                      uint32_t* __restrict__ merge_into,
-                                                                      scp_pair_stats* __restrict__ stats,
-                                                                      scp_stats_mirror* __restrict__ mirror,
-                                                                      unsigned long long seq) {
-  __shared__ int wsum[CMP1_THREADS / 64];
+// The body, for THREADS threads of ONE workgroup (all of them must call it): returns the number of set bits.
+// OVERWRITE: merge_into := map (every word, also the empty ones: the working-set bitmap of a NEW linearisation, no clearing
+// launch), map := 0.  COHERENT: the bits were set by other workgroups of the SAME kernel (the small-problem passes run this
+// as their tail): the words are read past this XCD's L2.
+template <int THREADS, bool COHERENT>
+__device__ inline int compact_small_body(uint32_t* __restrict__ map, int64_t words, int64_t nq, int64_t q_begin,
+                                         int64_t pairs, int64_t* __restrict__ rows, int64_t cap,
+                                         uint32_t* __restrict__ merge_into, bool overwrite) {
+  __shared__ int wsum[THREADS / 64];
   __shared__ int total_sh;
+  constexpr int CHUNK = THREADS * CMP_WPT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto load = [&](int64_t w) -> uint32_t {
+    return COHERENT ? __hip_atomic_load(map + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : map[w];
+  };
   // pass 1: the total (decides whether a merging pass may merge at all)
   int c_all = 0;
-  for (int64_t w = threadIdx.x; w < words; w += CMP1_THREADS) c_all += __popc(map[w]);
+  for (int64_t w = threadIdx.x; w < words; w += THREADS) c_all += __popc(load(w));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c_all += __shfl_xor(c_all, o);
+  __syncthreads();  // (wsum / total_sh of an earlier call in the same kernel have been read)
   if (lane == 0) wsum[wave] = c_all;
   __syncthreads();
   if (threadIdx.x == 0) {
     int t = 0;
-    for (int w = 0; w < CMP1_THREADS / 64; ++w) t += wsum[w];
+    for (int w = 0; w < THREADS / 64; ++w) t += wsum[w];
     total_sh = t;
   }
   __syncthreads();
   const int total = total_sh;
-  const bool overflow = merge_into != nullptr && (int64_t)total > cap;
+  const bool overflow = merge_into != nullptr && !overwrite && (int64_t)total > cap;
   // pass 2: chunk by chunk in row order, block scan per chunk
   int64_t carry = 0;
-  for (int64_t base = 0; base < words && total > 0; base += CMP1_WORDS) {
+  for (int64_t base = 0; base < words && (total > 0 || overwrite); base += CHUNK) {
     const int64_t w0 = base + (int64_t)threadIdx.x * CMP_WPT;
     uint32_t wd[CMP_WPT];
     int c = 0;
 #pragma unroll
     for (int i = 0; i < CMP_WPT; ++i) {
-      wd[i] = (w0 + i < words) ? map[w0 + i] : 0u;
+      wd[i] = (w0 + i < words) ? load(w0 + i) : 0u;
       c += __popc(wd[i]);
     }
     int incl = c;
@@ -1174,18 +1378,23 @@ __global__ __launch_bounds__(CMP1_THREADS) void compact_small_kernel(uint32_t* _
     __syncthreads();
     int before = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < CMP1_THREADS / 64; ++w) {
+    for (int w = 0; w < THREADS / 64; ++w) {
       if (w < wave) before += wsum[w];
       tot += wsum[w];
     }
     int64_t slot = carry + before + incl - c;
     carry += tot;
+    if (overwrite) {
+#pragma unroll
+      for (int i = 0; i < CMP_WPT; ++i)
+        if (w0 + i < words) merge_into[w0 + i] = wd[i];
+    }
     if (c == 0) continue;
 #pragma unroll
     for (int i = 0; i < CMP_WPT; ++i) {
       uint32_t m = wd[i];
       if (m && merge_into) {
-        if (!overflow) merge_into[w0 + i] |= m;
+        if (!overflow && !overwrite) merge_into[w0 + i] |= m;
         map[w0 + i] = 0u;
       }
       if (m) {
@@ -1207,6 +1416,17 @@ __global__ __launch_bounds__(CMP1_THREADS) void compact_small_kernel(uint32_t* _
       }
     }
   }
+  return total;
+}
+
+__global__ __launch_bounds__(CMP1_THREADS) void compact_small_kernel(uint32_t* __restrict__ map, int64_t words, int64_t nq,
+                                                                      int64_t q_begin, int64_t pairs,
+                                                                      int64_t* __restrict__ rows, int64_t cap,
+                                                                      uint32_t* __restrict__ merge_into,
+                                                                      scp_pair_stats* __restrict__ stats,
+                                                                      scp_stats_mirror* __restrict__ mirror,
+                                                                      unsigned long long seq) {
+  const int total = compact_small_body<CMP1_THREADS, false>(map, words, nq, q_begin, pairs, rows, cap, merge_into, false);
   if (threadIdx.x == 0) {
     stats->n_selected = (unsigned long long)total;
     publish_stats(stats, (unsigned long long)total, mirror, seq);
@@ -1315,8 +1535,9 @@ extern "C" int scp_select_pairs(scp_ctx* ctx, int N, int K, int D, double R, int
   const int64_t words = (K * nq + 31) / 32;
   rc = ensure_cmp(ctx, words);
   if (rc) return rc;
-  rc = launch_pair_pass<MODE_SELECT>(ctx, a, pos_prev, nullptr, nullptr, sel_bitmap, words);  // (its prep kernel clears the map)
-  if (rc) return rc;
+  PassTail tail{sel_rows, sel_cap, sel_bitmap, true, words, false};
+  rc = launch_pair_pass<MODE_SELECT>(ctx, a, pos_prev, nullptr, nullptr, sel_bitmap, words, &tail);  // (its prep kernel clears the map)
+  if (rc || tail.done) return rc;
   return launch_compaction(ctx, sel_bitmap, words, nq, q_begin, a.pairs, sel_rows, sel_cap, nullptr, stats);
 }
 
@@ -1391,7 +1612,8 @@ extern "C" int scp_check_avoidance(scp_ctx* ctx, int N, int K, int D, double R, 
   a.N = N; a.K = K; a.D = D; a.R = R; a.h = 0.0;
   a.q_begin = q_begin; a.q_end = q_end; a.pairs = scp_pairs(N);
   a.stats = stats;
-  return launch_pair_pass<MODE_CHECK>(ctx, a, pos, nullptr, nullptr);
+  PassTail tail{nullptr, 0, nullptr, false, (K * (q_end - q_begin) + 31) / 32, false};
+  return launch_pair_pass<MODE_CHECK>(ctx, a, pos, nullptr, nullptr, nullptr, 0, &tail);
 }
 
 extern "C" int scp_collision_violations(scp_ctx* ctx, int N, int K, int D, double h, int64_t q_begin,
@@ -1438,9 +1660,41 @@ extern "C" int scp_collision_violations_at(scp_ctx* ctx, int N, int K, int D, do
   if (rc) return rc;
   a.bitmap = sel_bitmap; a.mark = ctx->cmp_map; a.stats = stats;
   a.eta_stride = scp_eta_stride(K, nq);
-  rc = launch_pair_pass<MODE_VIOL_RECOMPUTE>(ctx, a, pos_prev, pos_new, nullptr);
-  if (rc) return rc;
+  PassTail tail{new_rows, new_cap, sel_bitmap, false, words, false};
+  rc = launch_pair_pass<MODE_VIOL_RECOMPUTE>(ctx, a, pos_prev, pos_new, nullptr, nullptr, 0, &tail);
+  if (rc || tail.done) return rc;
   return launch_compaction(ctx, ctx->cmp_map, words, nq, q_begin, a.pairs, new_rows, new_cap, sel_bitmap, stats);
+}
+
+// internal (scp_common.h): scp_qp_get_solution + scp_kinematics + scp_collision_violations_at of a SMALL problem in ONE
+// launch -- the pass derives the new positions from the QP's time-major solution x_tm itself and leaves them (pos_out) and
+// the solution in the reference layout (x_out) behind; bit-identical to the three calls.  *fused = false: not a small
+// problem, nothing was launched.
+int scp_violations_from_solution(scp_ctx* ctx, int N, int K, int D, double R, double h, int64_t q_begin, int64_t q_end,
+                                 const double* pos_prev, const double* x_tm, const double* p0, const double* v0, double* x_out,
+                                 double* pos_out, double feas_tol, int64_t* new_rows, int64_t new_cap, uint32_t* sel_bitmap,
+                                 scp_pair_stats* stats, bool* fused) {
+  *fused = false;
+  int rc = check_pair_range(ctx, N, K, D, q_begin, q_end);
+  if (rc) return rc;
+  const int64_t nq = q_end - q_begin;
+  if (!small_pass_ok(ctx, N, K, D, nq, 2)) return SCP_OK;
+  PairArgs a{};
+  a.N = N; a.K = K; a.D = D; a.R = R; a.h = h;
+  a.q_begin = q_begin; a.q_end = q_end; a.pairs = scp_pairs(N);
+  a.margin = feas_tol;
+  const int64_t words = (K * nq + 31) / 32;
+  rc = ensure_cmp(ctx, words);
+  if (rc) return rc;
+  a.bitmap = sel_bitmap; a.mark = ctx->cmp_map; a.stats = stats;
+  a.eta_stride = scp_eta_stride(K, nq);
+  a.x_tm = x_tm; a.p0 = p0; a.v0 = v0; a.x_out = x_out; a.pos_out = pos_out;
+  PassTail tail{new_rows, new_cap, sel_bitmap, false, words, false};
+  rc = launch_pair_pass<MODE_VIOL_RECOMPUTE>(ctx, a, pos_prev, nullptr, nullptr, nullptr, 0, &tail);
+  if (rc) return rc;
+  if (!tail.done) return scp_fail(ctx, SCP_ERR_STATE, "violations_from_solution: the small-problem pass did not run");
+  *fused = true;
+  return SCP_OK;
 }
 
 // ----------------------------------------------------------------------------------------------------

@@ -1258,6 +1258,8 @@ extern "C" int scp_qp_get_solution(scp_qp* qp, double* x_out) {
   return scp_launch_from_time_major(qp->ctx, qp->N, qp->K, qp->D, qp->d.x, x_out);
 }
 
+const double* scp_qp_solution_tm(const scp_qp* qp) { return qp->d.x; }
+
 extern "C" int scp_qp_get_duals(scp_qp* qp, double* y_fixed, double* y_col) {
   if (!qp) return SCP_ERR_INVALID;
   scp_ctx* ctx = qp->ctx;

@@ -34,6 +34,8 @@ struct StepState {
   scp_qp_info info;
   scp_qp_settings saved;
   bool active;
+  bool fuse_ok;           // all phases run inside one call (solve_joint_qp): a round's solution may stay in the QP's layout
+  bool solution_pending;  // ... until the violations pass derives x and its positions itself (small problems)
   double t0;            // wall clock at the start of the step
   double lim_copy[6], space_copy[6];  // sharded steps: the host arrays outlive the call that passed them
 };
@@ -76,7 +78,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 // stats of the pass just enqueued.  Passes that end in a row list (linearise, violations) publish them in the ctx's mapped
 // host mirror; the check pass has no trailing kernel, its stats are copied.
 int read_stats(scp_solver* s, bool from_mirror) {
-  if (from_mirror && s->pairs > 0) return scp_ctx_wait_stats(s->ctx, s->h_stats);
+  if ((from_mirror || s->ctx->last_pass_small) && s->pairs > 0) return scp_ctx_wait_stats(s->ctx, s->h_stats);
   SV_HIP(hipMemcpyAsync(s->h_stats, s->stats, sizeof(scp_pair_stats), hipMemcpyDeviceToHost, s->ctx->stream));
   SV_HIP(hipStreamSynchronize(s->ctx->stream));
   return SCP_OK;
@@ -243,9 +245,19 @@ int step_qp_round(scp_solver* s, StepState& t, const int64_t* rows, int64_t n, s
   rec->persist_launches += t.info.persist_launches;
   rec->persist_gave_up += t.info.persist_gave_up;
   rec->rho_switches_in_kernel += t.info.rho_switches_in_kernel;
+  if (t.fuse_ok) {  // (step_violations materialises s->x and s->pos_b, inside its pass when the problem is small)
+    t.solution_pending = true;
+    return SCP_OK;
+  }
   SV_CHECK(scp_qp_get_solution(s->qp, s->x));
   SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, s->x, t.p0, t.v0, s->pos_b, nullptr));
   return SCP_OK;
+}
+
+int materialise_solution(scp_solver* s, StepState& t) {
+  t.solution_pending = false;
+  SV_CHECK(scp_qp_get_solution(s->qp, s->x));
+  return scp_kinematics(s->ctx, s->N, s->K, s->D, s->h, s->x, t.p0, t.v0, s->pos_b, nullptr);
 }
 
 // phase 3 -- every row of [q_begin, q_end) checked at the round's solution; the violated rows outside the working set are
@@ -254,10 +266,26 @@ int step_violations(scp_solver* s, StepState& t, int64_t* n_new) {
   scp_ctx* ctx = s->ctx;
   *n_new = 0;
   if (t.q_end <= t.q_begin) {  // no pairs (a single agent, an empty shard): the pass's neutral element
+    if (t.solution_pending) SV_CHECK(materialise_solution(s, t));
     t.max_v = -INFINITY;
     return SCP_OK;
   }
   for (;;) {
+    if (t.solution_pending) {
+      bool fused = false;
+      SV_CHECK(scp_violations_from_solution(ctx, s->N, s->K, s->D, s->R, s->h, t.q_begin, t.q_end, s->pos_a,
+                                            scp_qp_solution_tm(s->qp), t.p0, t.v0, s->x, s->pos_b, t.o.feasibility_tol,
+                                            s->sel, s->sel_cap, s->bitmap, s->stats, &fused));
+      t.solution_pending = false;  // (s->x and s->pos_b exist from here on, also for a repeat with a longer list)
+      if (fused) {
+        SV_CHECK(read_stats(s, true));
+        if ((int64_t)s->h_stats->n_selected <= s->sel_cap) break;
+        SV_CHECK(grow_sel(s, (int64_t)s->h_stats->n_selected));
+        continue;
+      }
+      SV_CHECK(scp_qp_get_solution(s->qp, s->x));
+      SV_CHECK(scp_kinematics(ctx, s->N, s->K, s->D, s->h, s->x, t.p0, t.v0, s->pos_b, nullptr));
+    }
     SV_CHECK(scp_collision_violations_at(ctx, s->N, s->K, s->D, s->R, t.q_begin, t.q_end, s->pos_a, s->pos_b,
                                          t.o.feasibility_tol, s->sel, s->sel_cap, s->bitmap, s->stats));
     SV_CHECK(read_stats(s, true));
@@ -303,6 +331,7 @@ int solve_joint_qp(scp_solver* s, const double* acc_in, const double* limits, co
   const size_t nbytes = (size_t)s->N * s->K * s->D * sizeof(double);
   int64_t n = 0;
   SV_CHECK(step_linearize(s, t, acc_in, limits, space, p0, v0, pf, vf, o, eps, 0, s->pairs, rec, &n));
+  t.fuse_ok = true;
   if (o->max_rounds < 1) {  // no round runs: the "solution" is the linearisation point
     SV_CHECK(scp_qp_update_settings(s->qp, &s->st));
     SV_CHECK(scp_qp_reset(s->qp, acc_in));

@@ -121,7 +121,7 @@ ABI_VERSION = 4  # SCP_ABI_VERSION of include/scp_hip.h this binding matches (ch
 
 EXPORTS = [
     "scp_set_host_wait", "scp_abi_version", "scp_ctx_create", "scp_ctx_destroy", "scp_last_error", "scp_ctx_synchronize",
-    "scp_ctx_last_pair_ms", "scp_ctx_set_timing",
+    "scp_ctx_last_pair_ms", "scp_ctx_set_option",
     "scp_kinematics", "scp_fixed_bounds", "scp_linearize_pairs", "scp_select_pairs", "scp_check_avoidance", "scp_qp_add_rows_at",
     "scp_collision_violations", "scp_collision_violations_at", "scp_gather_rows", "scp_rel_step", "scp_qp_default_settings",
     "scp_qp_workspace_bytes", "scp_qp_create", "scp_qp_destroy", "scp_qp_update_settings", "scp_qp_set_problem",
@@ -159,8 +159,8 @@ def load_library():
                        f"{path}: ABI version {lib.scp_abi_version()}, this binding needs {ABI_VERSION} -- rebuild "
                        "(python -c 'import __graft_entry__ as g; g.build()')")
     lib.scp_set_host_wait.argtypes = [i32]
-    lib.scp_ctx_set_timing.argtypes = [vp, i32]
-    lib.scp_ctx_set_timing.restype = i32
+    lib.scp_ctx_set_option.argtypes = [vp, C.c_char_p, i32]
+    lib.scp_ctx_set_option.restype = i32
     lib.scp_set_host_wait.restype = None
     lib.scp_ctx_create.argtypes = [i32, vp, C.POINTER(vp)]
     lib.scp_ctx_destroy.argtypes = [vp]
@@ -262,10 +262,14 @@ class Context:
         self.h = h
         self.stats = torch.zeros(4, dtype=torch.float64, device=self.tdev)  # struct scp_pair_stats
 
+    def set_option(self, key, value):
+        """scp_ctx_set_option: "kernel_timing" (HIP events around the pairwise kernels and QP solves; 0 saves ~25 queue packets
+        per complete solve, the kernel times in the records then read 0 and solve_ms is host wall clock),
+        "single_launch_passes" (one-launch pairwise passes for small problems)"""
+        self.check(self.lib.scp_ctx_set_option(self.h, key.encode(), int(value)))
+
     def set_timing(self, on):
-        """HIP events around the pairwise kernels and QP solves on / off (scp_ctx_set_timing): off saves ~25 queue packets per
-        complete solve; the kernel times in the records then read 0, solve_ms is host wall clock"""
-        self.check(self.lib.scp_ctx_set_timing(self.h, 1 if on else 0))
+        self.set_option("kernel_timing", 1 if on else 0)
 
     def close(self):
         if getattr(self, "h", None):

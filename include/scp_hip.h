@@ -132,11 +132,15 @@ int scp_ctx_synchronize(scp_ctx* ctx);
 /* device time (ms) of the most recent pairwise kernel launch alone (scp_linearize_pairs, scp_check_avoidance,
  * scp_collision_violations), from HIP events recorded on the ctx stream around that launch; synchronises. */
 int scp_ctx_last_pair_ms(scp_ctx* ctx, float* ms);
-/* on = 0: no HIP events are recorded around the pairwise kernels and the QP solves (two queue packets each, ~25 per complete
- * solve): scp_ctx_last_pair_ms and the records' linearize_ms / violations_ms then read 0 and solve_ms is the host's wall
- * clock around the solve.  For many concurrent solver streams on one GPU (compute-trajectories-batch), where every packet
- * of a stream costs dispatch latency.  Default: on.  Results do not depend on it. */
-int scp_ctx_set_timing(scp_ctx* ctx, int on);
+/* Per-context switches; results never depend on them.
+ *   "kernel_timing" (default 1): HIP events around the pairwise kernels and the QP solves -- two queue packets each, ~25 per
+ *     complete solve.  0: none are recorded; scp_ctx_last_pair_ms and the records' linearize_ms / violations_ms then read 0
+ *     and solve_ms is the host's wall clock around the solve.  For many concurrent solver streams on one GPU
+ *     (compute-trajectories-batch), where every packet of a stream costs dispatch latency.
+ *   "single_launch_passes" (default 1): pairwise passes of small problems (<= 2 M collision rows) run as ONE launch -- staging
+ *     from the [N][K][D] arrays, reduction, sorted row list and host-visible stats in the pass kernel's last workgroup.
+ *     0: prep kernel + pass + compaction launches as for large problems. */
+int scp_ctx_set_option(scp_ctx* ctx, const char* key, int value);
 
 /* ---- a4 / a7: SCP._compute_positions_velocities (scp.py:371-397),
  *               SCP._accelerations_to_positions_velocities (scp.py:559-595) ---------------------------

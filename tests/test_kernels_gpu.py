@@ -247,6 +247,45 @@ def test_collision_violations_pass(ctx, N, K, D, seed, recompute):
         assert sorted(got.cpu().numpy().tolist()) == want and tiny.sel_cap >= len(want)
 
 
+@pytest.mark.parametrize("N,K,D,seed", [(2, 5, 2, 1), (3, 4, 3, 2), (33, 21, 3, 3), (96, 50, 2, 4), (128, 50, 2, 8), (65, 50, 3, 5),
+                                        (280, 6, 2, 24), (257, 41, 2, 9)])
+def test_single_launch_passes_equal_the_multi_launch_form(ctx, N, K, D, seed):
+    """Small problems run every pairwise pass as ONE launch (staging from the [N][K][D] arrays, per-workgroup partials, the
+    last workgroup reduces, compacts and publishes): same row lists, bitmaps and statistics as prep + pass + compaction."""
+    import torch
+    from path_planning import _hip
+
+    prob, acc = synth(N, K, D, seed)
+    pos, _ = so.kinematics(prob, acc)
+    x = acc + 0.2 * np.random.default_rng(seed + 1).standard_normal(acc.shape)
+    pos_new, _ = so.kinematics(prob, x)
+    pos_t, new_t, p0, v0 = ctx.tensor(pos), ctx.tensor(pos_new), ctx.tensor(prob.p0), ctx.tensor(prob.v0)
+    got = {}
+    try:
+        for flag in (1, 0):
+            ctx.set_option("single_launch_passes", flag)
+            pp = _hip.PairPass(ctx, N, K, D, prob.R, prob.h)
+            rows, md, fv = pp.select(pos_t, 0.2)
+            bm0 = pp.bitmap.clone()
+            new_rows, max_v = pp.violations(new_t, p0, v0, 1e-6)
+            again, max_v2 = pp.violations(new_t, p0, v0, 1e-6)
+            chk = ctx.check_avoidance(N, K, D, prob.R, new_t)
+            # a list that is too short: nothing merged, the repeat with a longer list finds the same rows
+            tiny = _hip.PairPass(ctx, N, K, D, prob.R, prob.h)
+            tiny.select(pos_t, 0.2)
+            tiny.sel_cap = 1
+            short, _ = tiny.violations(new_t, p0, v0, 1e-6)
+            got[flag] = (rows, md, fv, bm0, new_rows, max_v, again, max_v2, pp.bitmap.clone(), chk, short, tiny.bitmap.clone())
+    finally:
+        ctx.set_option("single_launch_passes", 1)
+    for u, v in zip(got[1], got[0]):
+        if torch.is_tensor(u):
+            assert torch.equal(u, v)
+        else:
+            assert u == v
+    assert got[1][6].numel() == 0
+
+
 def test_rel_step(ctx):
     rng = np.random.default_rng(5)
     a, b = rng.standard_normal(12345), rng.standard_normal(12345)

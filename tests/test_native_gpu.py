@@ -68,6 +68,33 @@ def test_native_loop_is_bit_identical(case):
         assert ia["iterations"][0]["working_rows"] > 4  # the QP workspace had to grow inside the native loop too
 
 
+@pytest.mark.parametrize("n,dim,seed", [(10, 2, 3), (64, 2, 64000), (128, 2, 128000), (27, 3, 17), (200, 2, 5)])
+def test_context_switches_do_not_change_results(n, dim, seed):
+    """scp_ctx_set_option: the one-launch pairwise passes of small problems (incl. the violations pass that derives x and its
+    positions from the QP's time-major solution) against the multi-launch form, and kernel timing off: identical solves."""
+    from path_planning.scenarios.position_generator import generate_grid_swap
+    from path_planning.solvers.scp import SCP
+
+    p0, pf, space = generate_grid_swap(n, seed=seed, dim=dim)
+    out = []
+    for opts in ({}, {"single_launch_passes": 0}, {"kernel_timing": 0}):
+        s = SCP(n, 10.0, 0.2, 0.8, space, dim=dim, verbose=False)
+        for k, v in opts.items():
+            s._ctx.set_option(k, v)
+        s.set_initial_states(p0)
+        s.set_final_states(pf)
+        out.append((s.generate_trajectories(15), s.last_info))
+    for t, info in out[1:]:
+        for key in ("positions", "velocities", "accelerations"):
+            np.testing.assert_array_equal(t[key], out[0][0][key])
+        assert info["n_iterations"] == out[0][1]["n_iterations"] and info["converged"] == out[0][1]["converged"]
+        for ra, rb in zip(info["iterations"], out[0][1]["iterations"]):
+            same_records(ra, rb)
+            assert ra["rel_step"] == rb["rel_step"]
+    assert out[2][1]["iterations"][0]["linearize_ms"] == 0.0 and out[2][1]["iterations"][0]["solve_ms"] > 0.0
+    assert out[0][1]["iterations"][0]["linearize_ms"] > 0.0
+
+
 def test_native_stdout_and_errors(capsys):
     """The reference's printed lines (scp.py:153-163, :446-447, :611-613) and its RuntimeError come out of the native
     loop exactly as out of the Python-driven one."""

@@ -40,7 +40,9 @@ struct scp_ctx {
   scp_stats_mirror* h_mirror;  // mapped host memory and its device address
   scp_stats_mirror* d_mirror;
   unsigned long long mirror_seq;  // sequence number of the latest compaction launch
-  unsigned long long* wg_part;    // [SCP_SMALL_MAX_WG][2] per-workgroup partials of a small-problem pairwise pass
+  unsigned long long* wg_part;    // [SCP_SMALL_MAX_WG][4] per-workgroup partials of a small-problem pairwise pass
+  uint32_t* wg_rows;              // [workgroups][8192] per-workgroup sub-lists of its marked rows (grown on demand)
+  size_t wg_rows_bytes;
   unsigned* d_ticket;             // its last-workgroup-done counter (zero between launches)
   int timing;                     // HIP events around the pairwise kernels and the QP solves (scp_ctx_set_option; default on)
   int small_pass;                 // one-launch pairwise passes for small problems (scp_ctx_set_option; default on)

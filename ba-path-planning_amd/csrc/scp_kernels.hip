@@ -40,7 +40,7 @@ extern "C" int scp_ctx_create(int device, void* hip_stream, scp_ctx** out) {
       hipHostGetDevicePointer((void**)&ctx->d_mirror, ctx->h_mirror, 0) != hipSuccess ||
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
       hipEventCreate(&ctx->pair_ev0) != hipSuccess || hipEventCreate(&ctx->pair_ev1) != hipSuccess ||
-      hipMalloc(&ctx->wg_part, 2 * SCP_SMALL_MAX_WG * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc(&ctx->wg_part, 4 * SCP_SMALL_MAX_WG * sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc(&ctx->d_ticket, 64) != hipSuccess || hipMemset(ctx->d_ticket, 0, 64) != hipSuccess) {
     delete ctx;
     return SCP_ERR_HIP;
@@ -74,6 +74,7 @@ extern "C" void scp_ctx_destroy(scp_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->d_scratch);
   if (ctx->wg_part) (void)hipFree(ctx->wg_part);
+  if (ctx->wg_rows) (void)hipFree(ctx->wg_rows);
   if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
   if (ctx->cmp_map) (void)hipFree(ctx->cmp_map);
   if (ctx->cmp_tot) (void)hipFree(ctx->cmp_tot);
@@ -210,6 +211,7 @@ __device__ inline void kin_point(const double* __restrict__ a, int64_t stride, i
   const double hkv = hk * vi;
   double p = pi + hkv;  // p0 + (h*k)*v0   scp.py:393
   const double hh = h * h;
+#pragma unroll 8  // (eight loads in flight; the sum stays in the reference's order)
   for (int j = 0; j < k; ++j) {
     const double aj = a[(int64_t)j * stride];
     const double hv = h * aj;
@@ -508,7 +510,8 @@ struct PairArgs {
   const double *p0, *v0;
   double* x_out;         // [N][K][D] copy of x_tm, and
   double* pos_out;       // [N][K][D] its positions (written by the first workgroup of every time step)
-  unsigned long long* wg_part;  // [workgroups][2]: per-workgroup (min distance | max violation, first violation)
+  unsigned long long* wg_part;  // [workgroups][4]: per-workgroup (min distance | max violation, first violation, marked rows, -)
+  uint32_t* wg_rows;     // [workgroups][PAIR_ROWS]: per-workgroup sorted sub-lists of the marked rows (offsets within the workgroup)
   unsigned* ticket;      // last-workgroup-done counter (self-resetting)
   int64_t* rows;         // tail: the sorted list of the marked rows, capacity `cap`
   int64_t cap;
@@ -644,10 +647,7 @@ constexpr int SCP_PAIR_CLK_WGS = 4096;
 __device__ unsigned long long scp_pair_clk[2 * SCP_PAIR_CLK_WGS];
 #endif
 
-template <int THREADS, bool COHERENT>
-__device__ inline int compact_small_body(uint32_t* __restrict__ map, int64_t words, int64_t nq, int64_t q_begin,
-                                         int64_t pairs, int64_t* __restrict__ rows, int64_t cap,
-                                         uint32_t* __restrict__ merge_into, bool overwrite);
+__device__ inline int block_exclusive_scan(int v, int* total);  // (256 threads; defined with the compaction kernels below)
 
 // SMALL (problems whose bitmap one workgroup compacts: <= 2 M rows, e.g. 128 agents x 50 steps): the pass is ONE launch.
 // Every workgroup stages its time step straight from the [N][K][D] arrays (no prep kernel) -- the violations pass can even
@@ -674,7 +674,10 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
 
   const double* P = NEED_P ? a.P_tm + (int64_t)k * N * D : nullptr;
   const double* Q = NEED_Q ? a.Q_tm + (int64_t)k * N * D : nullptr;
+  __shared__ uint32_t small_map_store[SMALL ? PAIR_ROWS / 32 : 1];
+  uint32_t* const small_map = small_map_store;
   if (SMALL) {
+    small_map[threadIdx.x] = 0u;  // (PAIR_ROWS / 32 == PAIR_THREADS words)
     double* sP = lds;
     double* sQ = lds + (NEED_P ? (int64_t)N * D : 0);
     const int C = N * D;
@@ -904,8 +907,13 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           if (sel[u][e]) {
-            const int64_t lr = slice0 + off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS) + e;
-            atomicOr(a.mark + (lr >> 5), 1u << (lr & 31));
+            if (SMALL) {  // (this workgroup's own PAIR_ROWS-bit map in LDS: compacted below, no global bitmap)
+              const int o = 2 * (int)threadIdx.x + (s0 + u) * (2 * PAIR_THREADS) + e;
+              atomicOr(small_map + (o >> 5), 1u << (o & 31));
+            } else {
+              const int64_t lr = slice0 + off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS) + e;
+              atomicOr(a.mark + (lr >> 5), 1u << (lr & 31));
+            }
           }
         }
       }
@@ -931,9 +939,19 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
     red_u[threadIdx.x >> 6] = my_first;
   }
   __syncthreads();
-  if (SMALL) {
+  if constexpr (SMALL) {
     __shared__ int last_sh;
+    __shared__ int woff[SCP_SMALL_MAX_WG + 1];
     const unsigned n_wg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+    // (a) this workgroup's marks -> its sorted sub-list (offsets within the workgroup's PAIR_ROWS rows)
+    int cnt_wg = 0;
+    if (MODE != MODE_CHECK) {
+      const uint32_t w = small_map[threadIdx.x];
+      int ex = block_exclusive_scan(__popc(w), &cnt_wg);
+      uint32_t* sub = a.wg_rows + (size_t)wg * PAIR_ROWS;
+      for (uint32_t m_ = w; m_; m_ &= m_ - 1)
+        __hip_atomic_store(sub + ex++, 32u * threadIdx.x + (uint32_t)(__ffs((int)m_) - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (threadIdx.x == 0) {
       double m = red_d[0];
       unsigned long long f = red_u[0];
@@ -942,37 +960,75 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
         m = VIOL ? fmax(m, red_d[w]) : fmin(m, red_d[w]);
         f = red_u[w] < f ? red_u[w] : f;
       }
-      __hip_atomic_store(a.wg_part + 2 * wg, (unsigned long long)__double_as_longlong(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.wg_part + 2 * wg + 1, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.wg_part + 4 * wg, (unsigned long long)__double_as_longlong(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.wg_part + 4 * wg + 1, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.wg_part + 4 * wg + 2, (unsigned long long)cnt_wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __threadfence();  // this thread's marks (and the partial) are visible device-wide ...
+    __threadfence();  // this thread's sub-list entries (and the partial) are visible device-wide ...
     __syncthreads();
     if (threadIdx.x == 0) last_sh = atomicAdd(a.ticket, 1u) == n_wg - 1 ? 1 : 0;  // ... before the ticket is taken
     __syncthreads();
     if (!last_sh) return;
     __threadfence();
-    // ---- tail: the last workgroup alone ----
+    // ---- (b) tail: the last workgroup alone.  Work ~ workgroups + marked rows, not ~ bitmap words ----
+    const bool merge = a.merge_into != nullptr;
+    if (MODE != MODE_CHECK && merge && a.overwrite)  // a new working set: the bitmap is rebuilt from nothing (atomics only:
+    {
+      for (int64_t w = threadIdx.x; w < a.words; w += PAIR_THREADS) atomicAnd(a.merge_into + w, 0u);  // same path as the ORs below)
+      __threadfence();  // (performed before any OR below is issued: barriers follow)
+    }
+    const int G = (int)((n_wg + PAIR_THREADS - 1) / PAIR_THREADS);  // consecutive workgroups per thread (<= 8)
     double m = VIOL ? -INF : INF;
     unsigned long long f = 0xFFFFFFFFFFFFFFFFULL;
-    for (unsigned w = threadIdx.x; w < n_wg; w += PAIR_THREADS) {
-      const double pm = __longlong_as_double((long long)__hip_atomic_load(a.wg_part + 2 * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      const unsigned long long pf = __hip_atomic_load(a.wg_part + 2 * w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      m = VIOL ? fmax(m, pm) : fmin(m, pm);
-      f = pf < f ? pf : f;
+    int cnt[SCP_SMALL_MAX_WG / PAIR_THREADS], mine = 0;
+#pragma unroll
+    for (int e = 0; e < SCP_SMALL_MAX_WG / PAIR_THREADS; ++e) {
+      const unsigned w = threadIdx.x * G + e;
+      cnt[e] = 0;
+      if (e < G && w < n_wg) {
+        const double pm = __longlong_as_double((long long)__hip_atomic_load(a.wg_part + 4 * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const unsigned long long pf = __hip_atomic_load(a.wg_part + 4 * w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cnt[e] = (int)__hip_atomic_load(a.wg_part + 4 * w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        m = VIOL ? fmax(m, pm) : fmin(m, pm);
+        f = pf < f ? pf : f;
+        mine += cnt[e];
+      }
     }
     m = VIOL ? wave_max(m) : wave_min(m);
     f = wave_min_u64(f);
-    __syncthreads();  // (red_d / red_u of this workgroup's own reduction have been read)
-    if ((threadIdx.x & 63) == 63) {
+    if ((threadIdx.x & 63) == 63) {  // (red_d / red_u of this workgroup's own reduction were read before the ticket barrier)
       red_d[threadIdx.x >> 6] = m;
       red_u[threadIdx.x >> 6] = f;
     }
     int total = 0;
-    if (MODE != MODE_CHECK)
-      total = compact_small_body<PAIR_THREADS, true>(a.mark, a.words, nq, a.q_begin, a.pairs, a.rows, a.cap, a.merge_into,
-                                                     a.overwrite != 0);
-    else
-      __syncthreads();
+    int run = block_exclusive_scan(mine, &total);  // (its barriers also order red_d / red_u and the bitmap clearing)
+#pragma unroll
+    for (int e = 0; e < SCP_SMALL_MAX_WG / PAIR_THREADS; ++e) {
+      const unsigned w = threadIdx.x * G + e;
+      if (e < G && w < n_wg) woff[w] = run;
+      run += cnt[e];
+    }
+    if (threadIdx.x == 0) woff[n_wg] = total;
+    __syncthreads();
+    if (MODE != MODE_CHECK) {
+      const bool overflow = merge && !a.overwrite && (int64_t)total > a.cap;  // (a merging pass merges all or nothing)
+      for (int sl = threadIdx.x; sl < total; sl += PAIR_THREADS) {
+        int lo = 0, hi = (int)n_wg;  // the workgroup whose sub-list holds slot sl: the last g with woff[g] <= sl
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (woff[mid] <= sl) lo = mid;
+          else hi = mid;
+        }
+        const uint32_t o = __hip_atomic_load(a.wg_rows + (size_t)lo * PAIR_ROWS + (sl - woff[lo]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t kg = lo / (int)gridDim.x, xg = lo % (int)gridDim.x;
+        const int64_t q_loc = xg * PAIR_ROWS - ((kg * nq) & 1) + (int64_t)o;  // pair offset within [q_begin, q_end)
+        if (!overflow && sl < a.cap) a.rows[sl] = kg * a.pairs + a.q_begin + q_loc;
+        if (merge && !overflow) {
+          const int64_t lr = kg * nq + q_loc;
+          atomicOr(a.merge_into + (lr >> 5), 1u << (lr & 31));
+        }
+      }
+    }
     if (threadIdx.x == 0) {
       m = red_d[0];
       f = red_u[0];
@@ -1104,8 +1160,21 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
     const size_t lds_small = (size_t)(MODE == MODE_VIOL_RECOMPUTE ? 2 : 1) * N * D * sizeof(double);
     if (small_pass_ok(ctx, N, K, D, nq, MODE == MODE_VIOL_RECOMPUTE ? 2 : 1)) {
       a.pos_a = pos_ref_layout;
-      if (MODE == MODE_SELECT) a.mark = ctx->cmp_map;  // (marks go to the self-cleaning scratch map; the tail turns them into the bitmap)
       if (MODE == MODE_VIOL_RECOMPUTE && !a.x_tm) a.pos_b = p0;
+      if (MODE != MODE_CHECK) {  // per-workgroup sub-lists of the marked rows (grown on demand, owned by the ctx)
+        const size_t need = (size_t)scp_cdiv(nq + 1, PAIR_ROWS) * K * PAIR_ROWS * sizeof(uint32_t);
+        if (ctx->wg_rows_bytes < need) {
+          if (ctx->wg_rows) {
+            SCP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            SCP_HIP_CHECK(ctx, hipFree(ctx->wg_rows));
+            ctx->wg_rows = nullptr;
+            ctx->wg_rows_bytes = 0;
+          }
+          SCP_HIP_CHECK(ctx, hipMalloc(&ctx->wg_rows, need));
+          ctx->wg_rows_bytes = need;
+        }
+      }
+      a.wg_rows = ctx->wg_rows;
       a.wg_part = ctx->wg_part;
       a.ticket = ctx->d_ticket;
       a.rows = tail->rows; a.cap = tail->cap; a.merge_into = tail->merge_into; a.overwrite = tail->overwrite ? 1 : 0;

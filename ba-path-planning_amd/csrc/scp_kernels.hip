@@ -2,6 +2,7 @@
 // pairwise passes (a5, a8, constraint generation) and the SCP relative step (a1).
 // Reference: /root/reference/src/path_planning/solvers/scp.py (line numbers cited per kernel).
 #include "scp_common.h"
+#include "scp_pair_device.h"
 
 #include <sys/prctl.h>
 #include <time.h>
@@ -148,6 +149,20 @@ int scp_ctx_wait_stats(scp_ctx* ctx, scp_pair_stats* out) {
   return SCP_OK;
 }
 
+// scp_rel_step's result from the partial sums the latest small-problem violations pass left in the mirror (call after
+// scp_ctx_wait_stats): the same sums in the same order as scp_rel_step's host side
+void scp_ctx_mirror_rel(scp_ctx* ctx, int64_t n, double* out) {
+  const int blocks = (int)((n + 256 * 8 - 1) / (256 * 8)) < 32 ? (int)((n + 256 * 8 - 1) / (256 * 8)) : 32;
+  double d2 = 0.0, b2 = 0.0;
+  for (int b = 0; b < blocks; ++b) {
+    d2 += ctx->h_mirror->rel[2 * b];
+    b2 += ctx->h_mirror->rel[2 * b + 1];
+  }
+  out[0] = std::sqrt(d2);
+  out[1] = std::sqrt(b2);
+  out[2] = out[0] / out[1];
+}
+
 extern "C" const char* scp_last_error(const scp_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 
 extern "C" int scp_ctx_synchronize(scp_ctx* ctx) {
@@ -200,6 +215,17 @@ int scp_launch_from_time_major(scp_ctx* ctx, int N, int K, int D, const double* 
 // reference's order with separately rounded multiply and add (no FMA) so the result is bitwise the
 // reference's.
 // ----------------------------------------------------------------------------------------------------
+// one term of scp_rel_step's two sums (scp.py:157-159): ONE definition for rel_step_partial_kernel and for the tail of the
+// small-problem violations pass, which emulates that kernel's blocks one after the other (same sums, same bits)
+__device__ inline void rel_accum(double x, double y, double& d2, double& b2) {
+  d2 += (x - y) * (x - y);
+  b2 += y * y;
+}
+__host__ __device__ inline int rel_step_blocks(int64_t n) {
+  const int b = (int)((n + 256 * 8 - 1) / (256 * 8));
+  return b < 32 ? b : 32;
+}
+
 // position (and velocity) of one coordinate at step k from its acceleration samples a[0], a[stride], ...: ONE definition for
 // the kinematics kernel and for the small-problem violations pass that derives its positions from the QP's time-major
 // solution itself (pair_pass_kernel<.., SMALL>), so that both produce the same bits
@@ -393,20 +419,6 @@ int scp_launch_bounds_time_major(scp_ctx* ctx, int N, int K, int D, double h, co
 // ----------------------------------------------------------------------------------------------------
 // pairwise passes
 // ----------------------------------------------------------------------------------------------------
-// Lexicographic pair index q -> (i, j), i < j.  Row i of the triangle starts at off(i) = i (2N - i - 1) / 2.
-__device__ __host__ inline int64_t tri_off(int64_t i, int64_t N) { return i * (2 * N - i - 1) / 2; }
-
-__device__ inline void decode_pair(int64_t q, int N, int& i, int& j) {
-  const double b = 2.0 * N - 1.0;
-  int64_t ii = (int64_t)((b - sqrt(b * b - 8.0 * (double)q)) * 0.5);
-  if (ii < 0) ii = 0;
-  if (ii > N - 2) ii = N - 2;
-  while (tri_off(ii, N) > q) --ii;
-  while (ii < N - 2 && tri_off(ii + 1, N) <= q) ++ii;
-  i = (int)ii;
-  j = (int)(q - tri_off(ii, N) + ii + 1);
-}
-
 // (called by thread 0 of the prep kernel that precedes every pairwise pass: one launch less per pass)
 __device__ inline void pair_stats_init(scp_pair_stats* s) {
   s->min_dist = __longlong_as_double(0x7FF0000000000000LL);
@@ -510,6 +522,8 @@ struct PairArgs {
   const double *p0, *v0;
   double* x_out;         // [N][K][D] copy of x_tm, and
   double* pos_out;       // [N][K][D] its positions (written by the first workgroup of every time step)
+  const double* rel_prev;  // [N][K][D] or NULL: the tail also leaves the partial sums of scp_rel_step(x_tm, rel_prev) in the mirror
+  int rel_blocks;
   unsigned long long* wg_part;  // [workgroups][4]: per-workgroup (min distance | max violation, first violation, marked rows, -)
   uint32_t* wg_rows;     // [workgroups][PAIR_ROWS]: per-workgroup sorted sub-lists of the marked rows (offsets within the workgroup)
   unsigned* ticket;      // last-workgroup-done counter (self-resetting)
@@ -521,10 +535,6 @@ struct PairArgs {
   scp_stats_mirror* mirror;
   unsigned long long seq;
 };
-
-// c_i[k] = p0 + (k h) v0: the free motion a row's lower bound is measured from (scp.py:543-549).  ONE definition for the
-// prep kernel of the passes and for the row-recomputing add kernel, so that both produce the same bits.
-__device__ inline double free_motion(double p0, double v0, int k, double h) { return p0 + ((double)k * h) * v0; }
 
 // [N][K][D] -> time-major P and Q = P - (p0 + (k h) v0) (either output may be NULL); also clears the bitmap the pass
 // is about to mark (linearize), so that no memset launch is needed
@@ -565,73 +575,6 @@ __device__ inline void pair_advance_far(int& i, int& j, int N, int s, int64_t q_
     ++i;
     if (j >= N) decode_pair(q_new < pairs ? q_new : pairs - 1, N, i, j);
   }
-}
-
-// 1/sqrt(x) to fp64 accuracy from the hardware seed: two Newton steps
-__device__ inline double rsqrt_nr(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  double hx = 0.5 * x;
-  y = y * fma(-hx * y, y, 1.5);
-  y = y * fma(-hx * y, y, 1.5);
-  return y;
-}
-
-template <int D>
-struct Pt {
-  double v[D];
-};
-
-template <int D>
-__device__ inline Pt<D> load_pt(const double* base, int idx) {
-  Pt<D> r;
-  if (D == 2) {
-    const double2 t = *reinterpret_cast<const double2*>(base + 2 * idx);
-    r.v[0] = t.x;
-    r.v[1] = t.y;
-  } else {
-#pragma unroll
-    for (int d = 0; d < D; ++d) r.v[d] = base[D * idx + d];
-  }
-  return r;
-}
-
-// Geometry of one pair at one time step and the compact row derived from it -- the arithmetic of scp.py:498-509, :543-549.
-// Shared by the pairwise passes and by add_rows_at_kernel (the row-free loop recomputes the selected rows with it): one
-// definition, the same bits.
-template <int D>
-struct PairGeom {
-  double diff[D], ss, inv, raw;
-  bool deg;
-};
-template <int D>
-__device__ inline PairGeom<D> pair_geom(const Pt<D>& Pi, const Pt<D>& Pj) {
-  PairGeom<D> g;
-  g.ss = 0.0;
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    g.diff[d] = Pi.v[d] - Pj.v[d];
-    g.ss = fma(g.diff[d], g.diff[d], g.ss);
-  }
-  g.deg = g.ss < 1e-12;  // dist < 1e-6 (scp.py:503)
-  g.inv = rsqrt_nr(fmax(g.ss, 1e-200));
-  double raw = g.ss * g.inv;
-  g.raw = fma(fma(-raw, raw, g.ss), 0.5 * g.inv, raw);  // one correction step: sqrt to < 1 ulp (0 stays 0)
-  return g;
-}
-// eta (scp.py:509; the fixed direction e_0 and dist := 1 for a degenerate pair, scp.py:503-507), the distance the row uses,
-// and  l = R + (eta.diff - dist) - eta.(c_i - c_j) = R - dist + eta.(Q_i - Q_j)  (scp.py:543-549)
-template <int D>
-__device__ inline void pair_row(const PairGeom<D>& g, const Pt<D>& Qi, const Pt<D>& Qj, double R, double (&eta)[D], double& l,
-                                double& dist) {
-  dist = g.deg ? 1.0 : g.raw;
-  double qd = 0.0;
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    const double e_d = g.deg ? (d == 0 ? 1.0 : 0.0) : g.diff[d] * g.inv;
-    eta[d] = e_d;
-    qd = fma(e_d, Qi.v[d] - Qj.v[d], qd);
-  }
-  l = (R - dist) + qd;
 }
 
 // One workgroup = PAIR_ROWS consecutive local rows of one time step k.  The k-slices of P and Q are staged in
@@ -1026,6 +969,37 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
         if (merge && !overflow) {
           const int64_t lr = kg * nq + q_loc;
           atomicOr(a.merge_into + (lr >> 5), 1u << (lr & 31));
+        }
+      }
+    }
+    if (MODE == MODE_VIOL_RECOMPUTE && a.rel_prev && a.mirror) {  // rel_step_partial_kernel, block after block
+      __shared__ double rs0[PAIR_THREADS / 64], rs1[PAIR_THREADS / 64];
+      const int64_t n = (int64_t)N * a.K * D, C = (int64_t)N * D;
+      for (int b = 0; b < a.rel_blocks; ++b) {
+        double d2 = 0.0, b2 = 0.0;
+        for (int64_t t = (int64_t)b * 256 + threadIdx.x; t < n; t += (int64_t)a.rel_blocks * 256) {
+          const int d = (int)(t % D), kk = (int)((t / D) % a.K);
+          const int64_t i = t / ((int64_t)D * a.K);
+          rel_accum(a.x_tm[(int64_t)kk * C + i * D + d], a.rel_prev[t], d2, b2);  // (x_out[t] = x_tm[k][c])
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          d2 += __shfl_xor(d2, o);
+          b2 += __shfl_xor(b2, o);
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+          rs0[threadIdx.x >> 6] = d2;
+          rs1[threadIdx.x >> 6] = b2;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          __hip_atomic_store((unsigned long long*)&a.mirror->rel[2 * b],
+                             (unsigned long long)__double_as_longlong((rs0[0] + rs0[1]) + (rs0[2] + rs0[3])), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store((unsigned long long*)&a.mirror->rel[2 * b + 1],
+                             (unsigned long long)__double_as_longlong((rs1[0] + rs1[1]) + (rs1[2] + rs1[3])), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }
@@ -1626,35 +1600,7 @@ __global__ __launch_bounds__(256) void add_rows_at_kernel(int N, int K, int64_t 
                                                            double* __restrict__ zc, double* __restrict__ yc) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n) return;
-  const int64_t r = rows[t];
-  const int k = (int)(r / pairs);
-  int i, j;
-  decode_pair(r % pairs, N, i, j);
-  Pt<D> Pi, Pj, Qi, Qj;
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    Pi.v[d] = pos_prev[((int64_t)i * K + k) * D + d];
-    Pj.v[d] = pos_prev[((int64_t)j * K + k) * D + d];
-    Qi.v[d] = Pi.v[d] - free_motion(p0[i * D + d], v0[i * D + d], k, h);
-    Qj.v[d] = Pj.v[d] - free_motion(p0[j * D + d], v0[j * D + d], k, h);
-  }
-  const PairGeom<D> g = pair_geom<D>(Pi, Pj);
-  double eta[D], l, dist;
-  pair_row<D>(g, Qi, Qj, R, eta, l, dist);
-  const int64_t o = base + t;
-  w_row[o] = r;
-  wk[o] = k;
-  wi[o] = i;
-  wj[o] = j;
-  double ax = 0.0;
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    weta[o * D + d] = eta[d];
-    ax += eta[d] * (Qx[(int64_t)k * C + (int64_t)i * D + d] - Qx[(int64_t)k * C + (int64_t)j * D + d]);
-  }
-  wl[o] = l;
-  zc[o] = fmax(ax, l);
-  yc[o] = 0.0;
+  add_row_at<D>(t, N, K, C, pairs, base, rows, pos_prev, p0, v0, R, h, Qx, w_row, wk, wi, wj, weta, wl, zc, yc);
 }
 
 int scp_launch_add_rows_at(scp_ctx* ctx, int N, int K, int D, int64_t base, int64_t n, const int64_t* rows,
@@ -1742,7 +1688,8 @@ extern "C" int scp_collision_violations_at(scp_ctx* ctx, int N, int K, int D, do
 int scp_violations_from_solution(scp_ctx* ctx, int N, int K, int D, double R, double h, int64_t q_begin, int64_t q_end,
                                  const double* pos_prev, const double* x_tm, const double* p0, const double* v0, double* x_out,
                                  double* pos_out, double feas_tol, int64_t* new_rows, int64_t new_cap, uint32_t* sel_bitmap,
-                                 scp_pair_stats* stats, bool* fused) {
+                                 scp_pair_stats* stats, const double* rel_prev, double* rel_out, bool* fused) {
+  (void)rel_out;
   *fused = false;
   int rc = check_pair_range(ctx, N, K, D, q_begin, q_end);
   if (rc) return rc;
@@ -1758,6 +1705,8 @@ int scp_violations_from_solution(scp_ctx* ctx, int N, int K, int D, double R, do
   a.bitmap = sel_bitmap; a.mark = ctx->cmp_map; a.stats = stats;
   a.eta_stride = scp_eta_stride(K, nq);
   a.x_tm = x_tm; a.p0 = p0; a.v0 = v0; a.x_out = x_out; a.pos_out = pos_out;
+  a.rel_prev = rel_prev;
+  a.rel_blocks = rel_step_blocks((int64_t)N * K * D);
   PassTail tail{new_rows, new_cap, sel_bitmap, false, words, false};
   rc = launch_pair_pass<MODE_VIOL_RECOMPUTE>(ctx, a, pos_prev, nullptr, nullptr, nullptr, 0, &tail);
   if (rc) return rc;
@@ -1813,9 +1762,7 @@ __global__ __launch_bounds__(256) void rel_step_partial_kernel(int64_t n, const 
   __shared__ double s0[4], s1[4];
   double d2 = 0.0, b2 = 0.0;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
-    const double x = a[t], y = b[t];
-    d2 += (x - y) * (x - y);
-    b2 += y * y;
+    rel_accum(a[t], b[t], d2, b2);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -1845,7 +1792,7 @@ __global__ __launch_bounds__(256) void rel_step_partial_kernel(int64_t n, const 
 extern "C" int scp_rel_step(scp_ctx* ctx, int64_t n, const double* a_new, const double* a_prev, double* out) {
   if (!ctx) return SCP_ERR_INVALID;
   SCP_REQUIRE(ctx, n > 0 && a_new && a_prev && out, "rel_step: bad arguments");
-  const int blocks = (int)((n + 256 * 8 - 1) / (256 * 8)) < 32 ? (int)((n + 256 * 8 - 1) / (256 * 8)) : 32;
+  const int blocks = rel_step_blocks(n);
   // the (at most 64) partial sums go straight to the mapped host scratch: no copy launch
   const unsigned long long seq = ++ctx->rel_seq;
   hipLaunchKernelGGL(rel_step_partial_kernel, dim3(blocks), dim3(256), 0, ctx->stream, n, a_new, a_prev,

@@ -835,7 +835,7 @@ extern "C" int scp_qp_create(scp_ctx* ctx, int N, int K, int D, double h, const 
   qp->row_cap = row_capacity;
   qp->nW = 0;
   qp->problem_set = qp->reset_done = false;
-  qp->cg1_ready = qp->csr_valid = qp->qx_fresh = false;
+  qp->cg1_ready = qp->csr_valid = qp->qx_fresh = qp->gval_valid = false;
   qp->qx_sel = 0;
   qp->rho = s->rho;
   carve(qp->d, workspace, K, qp->C, row_capacity, D);
@@ -983,6 +983,7 @@ extern "C" int scp_qp_reset(scp_qp* qp, const double* x0) {
   qp->steps_since_reset = 0;
   qp->rho = qp->st.rho;
   qp->cg1_ready = false;
+  qp->gval_valid = false;
   qp->csr_valid = false;
   qp->qx_fresh = one_launch;  // F x and S0 x of this x are in place
   QP_CHECK(build_kkt(qp));
@@ -996,6 +997,7 @@ extern "C" int scp_qp_set_rho(scp_qp* qp, double rho) {
   SCP_REQUIRE(qp->ctx, rho >= 1e-6 && rho <= 1e6, "qp_set_rho: rho out of range");
   qp->rho = rho;
   qp->cg1_ready = false;  // the carried row values depend on rho
+  qp->gval_valid = false;
   return build_kkt(qp);
 }
 
@@ -1025,6 +1027,15 @@ static int add_rows_impl(scp_qp* qp, int64_t n, const int64_t* rows, const doubl
     Qx = d.HQ + nx;
   }
   if (at) {
+    bool installed = false;
+    if (qp->st.use_mfma == 1 && qp->st.cg_iters == 1 && qp->K <= SCP_FUSED_MAX_K)  // (the single-step pipelines' lists)
+      QP_CHECK(scp_qp_install_rows_small(qp, n, rows, at->pos_prev, at->p0, at->v0, at->R, Qx, &installed));
+    if (installed) {
+      qp->nW += n;
+      qp->persist_cap_nW = -1;
+      qp->cg1_ready = false;
+      return SCP_OK;
+    }
     QP_CHECK(scp_launch_add_rows_at(ctx, qp->N, qp->K, qp->D, qp->nW, n, rows, at->pos_prev, at->p0, at->v0, at->R, qp->h, Qx,
                                     d.w_row, d.w_k, d.w_i, d.w_j, d.w_eta, d.w_l, d.zc, d.yc));
   } else {
@@ -1036,6 +1047,7 @@ static int add_rows_impl(scp_qp* qp, int64_t n, const int64_t* rows, const doubl
   qp->nW += n;
   qp->persist_cap_nW = -1;
   qp->cg1_ready = false;
+  qp->gval_valid = false;
   qp->csr_valid = false;
   return SCP_OK;
 }
@@ -1150,7 +1162,7 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
       } else {
         QP_CHECK(residuals(qp, with_dy));
       }
-      if (!cg1_it) { qp->cg1_ready = false; qp->qx_fresh = false; }  // residuals() used G and the Q slabs as scratch (the fused check keeps
+      if (!cg1_it) { qp->cg1_ready = false; qp->gval_valid = false; qp->qx_fresh = false; }  // residuals() used G and the Q slabs as scratch (the fused check keeps
                                            // the pipeline's carried state and refreshes S0 x, F x exactly)
       const double* hs = qp->h_scal;
       rp = hs[SL_RP];
@@ -1187,6 +1199,7 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
         if (nr > qp->rho * st.adaptive_rho_tolerance || nr < qp->rho / st.adaptive_rho_tolerance) {
           qp->rho = nr;
           qp->cg1_ready = false;  // the carried row values depend on rho
+          qp->gval_valid = false;
           QP_CHECK(build_kkt(qp));
           ++info->rho_updates;
         }
@@ -1243,6 +1256,7 @@ extern "C" int scp_qp_clone_state(scp_qp* dst, const scp_qp* src) {
   dst->st = src->st;
   dst->problem_set = true;
   dst->cg1_ready = false;
+  dst->gval_valid = false;
   dst->csr_valid = false;
   dst->qx_fresh = false;
   QP_CHECK(build_kkt(dst));

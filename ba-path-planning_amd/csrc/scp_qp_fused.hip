@@ -10,6 +10,7 @@
 // An ADMM step with n PCG steps is 4n + 3 launches, 7 at the default n = 1 (15n + ... on the generic path of scp_qp.hip, which stays as the fallback
 // for K > 128 and as the use_mfma = 0/2 reference); the arithmetic is the same, statement by statement.
 #include "scp_qp_device.h"
+#include "scp_pair_device.h"
 #include <cstdlib>
 
 namespace {
@@ -1207,11 +1208,21 @@ int scp_qp_qp0_iterations(scp_qp* qp, int nit, double* dy_out) {
 namespace {
 constexpr int CSR1_MAX_CELLS = 16384;
 constexpr int64_t CSR1_MAX_ROWS = 1 << 18;
-__global__ void csr_small_kernel(int64_t nW, int K, int ncell, int D, int64_t C, double rho, const int* __restrict__ wk,
-                                 const int* __restrict__ wi, const int* __restrict__ wj, const double* __restrict__ weta,
-                                 const double* __restrict__ Qx, const double* __restrict__ zc, const double* __restrict__ yc,
+// rows [base, base + n) that the kernel recomputes from the linearisation point first (scp_qp_add_rows_at); n = 0: none
+struct CsrNewRows {
+  int64_t n, base;
+  const int64_t* rows;
+  const double *pos_prev, *p0, *v0;
+  double R, h;
+  int N;
+  int64_t* w_row;
+  double* wl;
+};
+__global__ void csr_small_kernel(int64_t nW, int K, int ncell, int D, int64_t C, double rho, int* __restrict__ wk,
+                                 int* __restrict__ wi, int* __restrict__ wj, double* __restrict__ weta,
+                                 const double* __restrict__ Qx, double* __restrict__ zc, double* __restrict__ yc,
                                  int* __restrict__ ptr, int* __restrict__ ent, double* __restrict__ coef,
-                                 int* __restrict__ pos_i, int* __restrict__ pos_j, double* __restrict__ gval);
+                                 int* __restrict__ pos_i, int* __restrict__ pos_j, double* __restrict__ gval, CsrNewRows nr);
 }  // namespace
 
 // Bring the single-step pipeline's carried state in line with (x, zc, yc, rho): S0 x and F x exact, row values g.
@@ -1223,16 +1234,24 @@ int scp_qp_cg1_prepare(scp_qp* qp) {
   const double rho_c = qp->rho * qp->st.rho_col_scale;
   if (!qp->qx_fresh) {
     qp->qx_sel = 0;
+    qp->gval_valid = false;
     int rc = scp_launch_gemm(qp->ctx, 1, K, K, (int)C, 1.0, d.S0, d.x, 0.0, d.HQ + nx);
     if (!rc) rc = scp_launch_gemm(qp->ctx, 1, qp->Rf, K, (int)C, 1.0, d.F, d.x, 0.0, d.fx);
     if (rc) return rc;
   }
   qp->qx_fresh = false;
   const double* Qx = qp->qx_sel ? d.HQ : d.HQ + nx;
+  if (qp->csr_valid && qp->gval_valid && qp->gval_rho_c == rho_c) {  // scp_qp_install_rows_small built lists and values already
+    qp->gval_valid = false;  // (the iterations about to run carry them on)
+    qp->cg1_ready = true;
+    return SCP_OK;
+  }
+  qp->gval_valid = false;
   if (!qp->csr_valid && qp->nW > 0 && qp->nW <= CSR1_MAX_ROWS && qp->N * K <= CSR1_MAX_CELLS) {
     const int ncell = qp->N * K;
     hipLaunchKernelGGL(csr_small_kernel, dim3(1), dim3(1024), (size_t)ncell * sizeof(int), s, qp->nW, K, ncell, qp->D, C, rho_c,
-                       d.w_k, d.w_i, d.w_j, d.w_eta, Qx, d.zc, d.yc, d.cell_ptr, d.ent_code, d.coef, d.pos_i, d.pos_j, d.gval);
+                       d.w_k, d.w_i, d.w_j, d.w_eta, Qx, d.zc, d.yc, d.cell_ptr, d.ent_code, d.coef, d.pos_i, d.pos_j, d.gval,
+                       CsrNewRows{});
     FUSED_LAUNCHED(qp);
     qp->csr_valid = true;
     qp->cg1_ready = true;
@@ -1251,6 +1270,27 @@ int scp_qp_cg1_prepare(scp_qp* qp) {
                        d.zc, d.yc, d.pos_i, d.pos_j, d.gval);
   FUSED_LAUNCHED(qp);
   qp->cg1_ready = true;
+  return SCP_OK;
+}
+
+int scp_qp_install_rows_small(scp_qp* qp, int64_t n, const int64_t* rows, const double* pos_prev, const double* p0,
+                              const double* v0, double R, const double* Qx, bool* done) {
+  *done = false;
+  const QpDev& d = qp->d;
+  const int K = qp->K;
+  const int64_t nW = qp->nW + n;
+  if (!qp->qx_fresh || n <= 0 || nW > CSR1_MAX_ROWS || qp->N * K > CSR1_MAX_CELLS) return SCP_OK;
+  const int ncell = qp->N * K;
+  const double rho_c = qp->rho * qp->st.rho_col_scale;
+  CsrNewRows nr{n, qp->nW, rows, pos_prev, p0, v0, R, qp->h, qp->N, d.w_row, d.w_l};
+  hipLaunchKernelGGL(csr_small_kernel, dim3(1), dim3(1024), (size_t)ncell * sizeof(int), qp->ctx->stream, nW, K, ncell, qp->D,
+                     qp->C, rho_c, d.w_k, d.w_i, d.w_j, d.w_eta, Qx, d.zc, d.yc, d.cell_ptr, d.ent_code, d.coef, d.pos_i,
+                     d.pos_j, d.gval, nr);
+  FUSED_LAUNCHED(qp);
+  qp->csr_valid = true;
+  qp->gval_valid = true;
+  qp->gval_rho_c = rho_c;
+  *done = true;
   return SCP_OK;
 }
 
@@ -1432,17 +1472,30 @@ __global__ __launch_bounds__(256) void csr_finish_kernel(int64_t nent, int D, co
 // finish -- and the first row values (rows_value_kernel<D, true>) in ONE workgroup; the cell counters live in LDS.  Same lists,
 // same order as the five-launch build.
 __global__ __launch_bounds__(1024) void csr_small_kernel(int64_t nW, int K, int ncell, int D, int64_t C, double rho,
-                                                          const int* __restrict__ wk, const int* __restrict__ wi,
-                                                          const int* __restrict__ wj, const double* __restrict__ weta,
-                                                          const double* __restrict__ Qx, const double* __restrict__ zc,
-                                                          const double* __restrict__ yc, int* __restrict__ ptr,
+                                                          int* __restrict__ wk, int* __restrict__ wi,
+                                                          int* __restrict__ wj, double* __restrict__ weta,
+                                                          const double* __restrict__ Qx, double* __restrict__ zc,
+                                                          double* __restrict__ yc, int* __restrict__ ptr,
                                                           int* __restrict__ ent, double* __restrict__ coef,
                                                           int* __restrict__ pos_i, int* __restrict__ pos_j,
-                                                          double* __restrict__ gval) {
+                                                          double* __restrict__ gval, CsrNewRows nr) {
   extern __shared__ int csr_cnt[];  // [ncell]: counts, then exclusive offsets, then fill cursors (= end of each cell)
   __shared__ int wsum[16];
   constexpr int SC = CSR1_MAX_CELLS / 1024;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (nr.n > 0) {  // scp_qp_add_rows_at's kernel first: the new rows [base, base + n) from the linearisation point
+    const int64_t pairs = (int64_t)nr.N * (nr.N - 1) / 2;
+    for (int64_t t = tid; t < nr.n; t += 1024) {
+      if (D == 2)
+        add_row_at<2>(t, nr.N, K, C, pairs, nr.base, nr.rows, nr.pos_prev, nr.p0, nr.v0, nr.R, nr.h, Qx, nr.w_row, wk, wi, wj,
+                      weta, nr.wl, zc, yc);
+      else
+        add_row_at<3>(t, nr.N, K, C, pairs, nr.base, nr.rows, nr.pos_prev, nr.p0, nr.v0, nr.R, nr.h, Qx, nr.w_row, wk, wi, wj,
+                      weta, nr.wl, zc, yc);
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
   for (int c = tid; c < ncell; c += 1024) csr_cnt[c] = 0;
   __syncthreads();
   for (int64_t n = tid; n < nW; n += 1024) {

@@ -67,6 +67,8 @@ struct scp_qp {
   int64_t row_cap, nW;
   bool problem_set, reset_done;
   bool cg1_ready;  // carried state (Qx, gval) of the single-step pipeline matches (x, zc, yc, rho)
+  bool gval_valid;   // the incidence lists and row values were built together with the latest rows (scp_qp_install_rows_small)
+  double gval_rho_c; // ... at this column rho: scp_qp_cg1_prepare has nothing left to launch
   bool csr_valid;  // incidence lists match the working set
   bool qx_fresh;   // the current S0 x buffer and the F x slab are exact for x (written by the fused residual kernel)
   int qx_sel;      // which half of HQ holds S0 x (the single-step pipeline ping-pongs: 0 -> rows [K, 2K), 1 -> [0, K))
@@ -130,6 +132,10 @@ int scp_qp_csr_build(scp_qp* qp);
 // G = A_W^T g, g = (rho zc - yc) - rho A_W v (init) or rho A_W v with Q = S0 v: deterministic (gather over the incidence lists)
 int scp_qp_rows_gather(scp_qp* qp, bool init, const double* Q);
 int scp_qp_cg1_prepare(scp_qp* qp);
+// small problems: working rows [nW, nW + n) recomputed from the linearisation point (scp_qp_add_rows_at) AND the incidence
+// lists + row values of all nW + n rows in ONE launch; *done = false: not eligible, nothing was launched
+int scp_qp_install_rows_small(scp_qp* qp, int64_t n, const int64_t* rows, const double* pos_prev, const double* p0,
+                              const double* v0, double R, const double* Qx, bool* done);
 constexpr int SCP_SYNC_WORDS = 16;  // u64: give-up word | scratch
 // Workgroups of a persistent launch: at most one per CU (all resident), and the exchange buffers below are sized for
 // exactly this many (+1: the fault-injection hook announces one workgroup more than it launches).

@@ -36,6 +36,8 @@ struct StepState {
   bool active;
   bool fuse_ok;           // all phases run inside one call (solve_joint_qp): a round's solution may stay in the QP's layout
   bool solution_pending;  // ... until the violations pass derives x and its positions itself (small problems)
+  bool rel_ready;         // that pass also left scp_rel_step(x, acc_in) behind: rel[]
+  double rel[3];
   double t0;            // wall clock at the start of the step
   double lim_copy[6], space_copy[6];  // sharded steps: the host arrays outlive the call that passed them
 };
@@ -275,10 +277,12 @@ int step_violations(scp_solver* s, StepState& t, int64_t* n_new) {
       bool fused = false;
       SV_CHECK(scp_violations_from_solution(ctx, s->N, s->K, s->D, s->R, s->h, t.q_begin, t.q_end, s->pos_a,
                                             scp_qp_solution_tm(s->qp), t.p0, t.v0, s->x, s->pos_b, t.o.feasibility_tol,
-                                            s->sel, s->sel_cap, s->bitmap, s->stats, &fused));
+                                            s->sel, s->sel_cap, s->bitmap, s->stats, t.acc_in, t.rel, &fused));
       t.solution_pending = false;  // (s->x and s->pos_b exist from here on, also for a repeat with a longer list)
       if (fused) {
         SV_CHECK(read_stats(s, true));
+        scp_ctx_mirror_rel(ctx, (int64_t)s->N * s->K * s->D, t.rel);
+        t.rel_ready = true;
         if ((int64_t)s->h_stats->n_selected <= s->sel_cap) break;
         SV_CHECK(grow_sel(s, (int64_t)s->h_stats->n_selected));
         continue;
@@ -501,7 +505,8 @@ extern "C" int scp_solver_solve(scp_solver* s, const double* limits, const doubl
     SV_CHECK(solve_joint_qp(s, acc, limits, space, p0, v0, pf, vf, o, 0.0, rec));
     if (o->carry_rho) s->rho_start = rec->rho;  // the next linearisation's QP starts where this one ended
     double rel[3];
-    SV_CHECK(scp_rel_step(ctx, (int64_t)N * K * D, s->x, acc, rel));  // scp.py:157-159 (no zero guard)
+    if (s->step->rel_ready) memcpy(rel, s->step->rel, sizeof(rel));  // (left behind by the last violations pass: small problems)
+    else SV_CHECK(scp_rel_step(ctx, (int64_t)N * K * D, s->x, acc, rel));  // scp.py:157-159 (no zero guard)
     rec->rel_step = rel[2];
     rec->time_sec = now_s() - t_it;
     ++res->n_records;
@@ -553,7 +558,8 @@ extern "C" int scp_solver_step(scp_solver* s, const double* limits, const double
   SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, acc_in, p0, v0, s->pos_a, nullptr));
   SV_CHECK(solve_joint_qp(s, acc_in, limits, space, p0, v0, pf, vf, o, 0.0, rec));
   double rel[3];
-  SV_CHECK(scp_rel_step(ctx, (int64_t)N * K * D, s->x, acc_in, rel));  // scp.py:157-159
+  if (s->step->rel_ready) memcpy(rel, s->step->rel, sizeof(rel));
+  else SV_CHECK(scp_rel_step(ctx, (int64_t)N * K * D, s->x, acc_in, rel));  // scp.py:157-159
   rec->rel_step = rel[2];
   SV_HIP(hipMemcpyAsync(acc_out, s->x, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
   SV_HIP(hipStreamSynchronize(ctx->stream));

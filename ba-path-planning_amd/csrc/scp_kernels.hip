@@ -627,6 +627,16 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
     for (int c = threadIdx.x; c < C; c += PAIR_THREADS) {
       const int i = c / D, d = c - i * D;
       const int64_t g = ((int64_t)i * a.K + k) * D + d;
+      if (MODE == MODE_SELECT && a.x_tm) {  // the pass's positions are the kinematics of the QP's solution (after QP#0)
+        double pn, vn;
+        kin_point(a.x_tm + c, C, k, a.h, a.p0[c], a.v0[c], pn, vn);
+        if (blockIdx.x == 0) {
+          a.pos_out[g] = pn;
+          a.x_out[g] = a.x_tm[(int64_t)k * C + c];
+        }
+        sP[c] = pn;
+        continue;
+      }
       const double pa = a.pos_a[g];
       if (NEED_P) sP[c] = pa;
       if (MODE == MODE_VIOL_RECOMPUTE) {
@@ -1018,6 +1028,21 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
       st.max_violation = VIOL ? m : -INF;
       *a.stats = st;
       *a.ticket = 0u;  // (the next launch on this stream starts after this kernel has ended)
+      if (a.mirror && MODE == MODE_SELECT && a.x_tm && f != 0xFFFFFFFFFFFFFFFFULL) {
+        // the two positions of the first violating pair (scp.py:611-613 prints their distance): written by other workgroups
+        // of this kernel, hence read past this XCD's L2
+        const int64_t kf = (int64_t)(f / (unsigned long long)a.pairs);
+        int fi, fj;
+        decode_pair((int64_t)(f % (unsigned long long)a.pairs), N, fi, fj);
+        for (int d = 0; d < D; ++d) {
+          const unsigned long long vi = __hip_atomic_load((const unsigned long long*)(a.pos_out + ((int64_t)fi * a.K + kf) * D + d),
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long vj = __hip_atomic_load((const unsigned long long*)(a.pos_out + ((int64_t)fj * a.K + kf) * D + d),
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store((unsigned long long*)&a.mirror->pts[d], vi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store((unsigned long long*)&a.mirror->pts[3 + d], vj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
       if (a.mirror) {
         __hip_atomic_store((unsigned long long*)&a.mirror->stats.min_dist, (unsigned long long)__double_as_longlong(st.min_dist),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1711,6 +1736,34 @@ int scp_violations_from_solution(scp_ctx* ctx, int N, int K, int D, double R, do
   rc = launch_pair_pass<MODE_VIOL_RECOMPUTE>(ctx, a, pos_prev, nullptr, nullptr, nullptr, 0, &tail);
   if (rc) return rc;
   if (!tail.done) return scp_fail(ctx, SCP_ERR_STATE, "violations_from_solution: the small-problem pass did not run");
+  *fused = true;
+  return SCP_OK;
+}
+
+// internal (scp_common.h): scp_qp_get_solution + scp_kinematics + scp_check_avoidance + scp_select_pairs of a SMALL problem
+// in ONE launch (after QP#0): the select pass stages the kinematics of the QP's time-major solution, leaves positions and
+// solution in the reference layout behind, reduces the a8 statistics (the same ones the check pass reduces) and, for the
+// reference's print, leaves the two positions of the first violating pair in the mirror.
+int scp_select_from_solution(scp_ctx* ctx, int N, int K, int D, double R, double h, int64_t q_begin, int64_t q_end,
+                             const double* x_tm, const double* p0, const double* v0, double* x_out, double* pos_out,
+                             double margin, int64_t* sel_rows, int64_t sel_cap, uint32_t* sel_bitmap, scp_pair_stats* stats,
+                             bool* fused) {
+  *fused = false;
+  int rc = check_pair_range(ctx, N, K, D, q_begin, q_end);
+  if (rc) return rc;
+  const int64_t nq = q_end - q_begin;
+  if (!small_pass_ok(ctx, N, K, D, nq, 1)) return SCP_OK;
+  PairArgs a{};
+  a.N = N; a.K = K; a.D = D; a.R = R; a.h = h;
+  a.q_begin = q_begin; a.q_end = q_end; a.pairs = scp_pairs(N);
+  a.margin = margin;
+  a.bitmap = sel_bitmap; a.mark = sel_bitmap; a.stats = stats;
+  a.eta_stride = scp_eta_stride(K, nq);
+  a.x_tm = x_tm; a.p0 = p0; a.v0 = v0; a.x_out = x_out; a.pos_out = pos_out;
+  PassTail tail{sel_rows, sel_cap, sel_bitmap, true, (K * nq + 31) / 32, false};
+  rc = launch_pair_pass<MODE_SELECT>(ctx, a, nullptr, nullptr, nullptr, nullptr, 0, &tail);
+  if (rc) return rc;
+  if (!tail.done) return scp_fail(ctx, SCP_ERR_STATE, "select_from_solution: the small-problem pass did not run");
   *fused = true;
   return SCP_OK;
 }

@@ -62,6 +62,11 @@ struct scp_solver {
   // trajectories [N][K][D]
   double *acc, *x, *pos_a, *pos_b, *vel;
   double* pair_pts;  // pinned, 2 D doubles: the two positions of the first violation
+  // the selection of the NEXT linearisation is already in sel / bitmap (small problems: produced by the pass that computed
+  // the positions it linearises around); consumed by step_linearize
+  bool spec_valid;
+  int64_t spec_n;
+  double spec_margin;
   double rho_start;  // > 0: the joint QP of the next step starts at this rho (options.carry_rho), else at settings.rho
   struct StepState* step;  // the SCP iteration in flight (phases of solve_joint_qp / of the sharded entry points)
 };
@@ -202,6 +207,12 @@ int step_linearize(scp_solver* s, StepState& t, const double* acc_in, const doub
   }
   memset(rec, 0, sizeof(*rec));
   if (!t.row_free) SV_CHECK(ensure_row_planes(s));
+  const bool spec = s->spec_valid && t.row_free && q_begin == 0 && q_end == s->pairs && s->spec_margin == o->working_set_margin;
+  s->spec_valid = false;
+  if (spec) {  // (the pass that produced s->pos_a also selected around it: same list, same bitmap)
+    *n_sel = s->spec_n;
+    return SCP_OK;
+  }
   for (;;) {
     if (t.row_free)
       SV_CHECK(scp_select_pairs(ctx, N, K, D, s->R, q_begin, q_end, s->pos_a, o->working_set_margin, s->sel, s->sel_cap,
@@ -445,6 +456,7 @@ extern "C" int scp_solver_solve(scp_solver* s, const double* limits, const doubl
   memset(res, 0, sizeof(*res));
   res->first_violation = UINT64_MAX;
   const double t_start = now_s();
+  s->spec_valid = false;
 
   // a2 + a3: bounds, QP#0 (scp.py:137-138, :323-369)
   SV_CHECK(scp_qp_set_problem(s->qp, limits, space, p0, v0, pf, vf));
@@ -467,12 +479,23 @@ extern "C" int scp_solver_solve(scp_solver* s, const double* limits, const doubl
     return SCP_OK;
   }
   res->qp0_status = i0.status_val;
-  SV_CHECK(scp_qp_get_solution(s->qp, s->acc));
 
   // a4 + a8: initial guess, avoidance check evaluated ONCE (scp.py:140-144, never refreshed inside the loop :152)
-  SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, s->acc, p0, v0, s->pos_a, nullptr));
-  SV_CHECK(scp_check_avoidance(ctx, N, K, D, s->R, 0, s->pairs, s->pos_a, s->stats));
-  SV_CHECK(read_stats(s, false));
+  bool from_solution = false;
+  if (o->row_free)  // small problems: solution -> acc, positions, the a8 statistics AND the first selection in one launch
+    SV_CHECK(scp_select_from_solution(ctx, N, K, D, s->R, s->h, 0, s->pairs, scp_qp_solution_tm(s->qp), p0, v0, s->acc, s->pos_a,
+                                      o->working_set_margin, s->sel, s->sel_cap, s->bitmap, s->stats, &from_solution));
+  if (from_solution) {
+    SV_CHECK(read_stats(s, true));
+    s->spec_valid = (int64_t)s->h_stats->n_selected <= s->sel_cap;
+    s->spec_n = (int64_t)s->h_stats->n_selected;
+    s->spec_margin = o->working_set_margin;
+  } else {
+    SV_CHECK(scp_qp_get_solution(s->qp, s->acc));
+    SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, s->acc, p0, v0, s->pos_a, nullptr));
+    SV_CHECK(scp_check_avoidance(ctx, N, K, D, s->R, 0, s->pairs, s->pos_a, s->stats));
+    SV_CHECK(read_stats(s, false));
+  }
   bool is_feasible = s->h_stats->first_violation == UINT64_MAX;
   res->first_violation = s->h_stats->first_violation;
   if (!is_feasible && s->pairs > 0) {  // distance of the first violating pair, for the reference's print (scp.py:611-613)
@@ -484,9 +507,13 @@ extern "C" int scp_solver_solve(scp_solver* s, const double* limits, const doubl
     while (i * (2LL * N - i - 1) / 2 > q) --i;
     while (i < N - 2 && (i + 1) * (2LL * N - i - 2) / 2 <= q) ++i;
     const int64_t j = q - i * (2LL * N - i - 1) / 2 + i + 1;
-    SV_HIP(hipMemcpyAsync(s->pair_pts, s->pos_a + ((size_t)i * K + k) * D, D * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SV_HIP(hipMemcpyAsync(s->pair_pts + 3, s->pos_a + ((size_t)j * K + k) * D, D * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SV_HIP(hipStreamSynchronize(ctx->stream));
+    if (from_solution) {  // (the pass left the two points in the mirror)
+      memcpy(s->pair_pts, ctx->h_mirror->pts, 6 * sizeof(double));
+    } else {
+      SV_HIP(hipMemcpyAsync(s->pair_pts, s->pos_a + ((size_t)i * K + k) * D, D * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      SV_HIP(hipMemcpyAsync(s->pair_pts + 3, s->pos_a + ((size_t)j * K + k) * D, D * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      SV_HIP(hipStreamSynchronize(ctx->stream));
+    }
     double d2 = 0.0;
     for (int d = 0; d < D; ++d) d2 += (s->pair_pts[d] - s->pair_pts[3 + d]) * (s->pair_pts[d] - s->pair_pts[3 + d]);
     res->first_violation_distance = std::sqrt(d2);
@@ -554,6 +581,7 @@ extern "C" int scp_solver_step(scp_solver* s, const double* limits, const double
   const size_t nbytes = (size_t)N * K * D * sizeof(double);
   const double t0 = now_s();
   s->rho_start = 0.0;
+  s->spec_valid = false;
   SV_CHECK(scp_qp_set_problem(s->qp, limits, space, p0, v0, pf, vf));
   SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, acc_in, p0, v0, s->pos_a, nullptr));
   SV_CHECK(solve_joint_qp(s, acc_in, limits, space, p0, v0, pf, vf, o, 0.0, rec));
@@ -593,6 +621,7 @@ extern "C" int scp_solver_shard_begin(scp_solver* s, const double* limits, const
   StepState& t = *s->step;
   step_restore(s, t);
   s->rho_start = 0.0;
+  s->spec_valid = false;
   double lim[6], spc[6];
   memcpy(lim, limits, sizeof(lim));
   memcpy(spc, space, 2 * D * sizeof(double));

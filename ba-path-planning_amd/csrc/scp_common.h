@@ -12,6 +12,7 @@
 // mapped host copy of the stats of the latest pass that produced a row list (written by its last kernel, seq last)
 struct scp_stats_mirror {
   scp_pair_stats stats;
+  unsigned long long n_spec;  // small-problem violations pass from a solution: rows of its speculative selection
   double pts[6];   // small-problem select pass from a QP solution: the two positions of the first violating pair
   double rel[64];  // small-problem violations pass: the partial sums of scp_rel_step(x_new, x_prev), block by block
   volatile unsigned long long seq;
@@ -96,9 +97,10 @@ int scp_ctx_wait_stats(scp_ctx* ctx, scp_pair_stats* out);
 int scp_violations_from_solution(scp_ctx* ctx, int N, int K, int D, double R, double h, int64_t q_begin, int64_t q_end,
                                  const double* pos_prev, const double* x_tm, const double* p0, const double* v0, double* x_out,
                                  double* pos_out, double feas_tol, int64_t* new_rows, int64_t new_cap, uint32_t* sel_bitmap,
-                                 scp_pair_stats* stats, const double* rel_prev /* [N][K][D] or NULL */, double* rel_out /* [3] */,
-                                 bool* fused);
-// (rel_out is filled by scp_ctx_wait_rel after the pass's stats have arrived)
+                                 scp_pair_stats* stats, const double* rel_prev /* [N][K][D] or NULL */,
+                                 int64_t* spec_rows /* or NULL: + the selection around the new positions */, int64_t spec_cap,
+                                 uint32_t* spec_bitmap, double spec_margin, bool* fused);
+// scp_rel_step's numbers from the sums that pass left in the mirror (after its stats have arrived)
 void scp_ctx_mirror_rel(scp_ctx* ctx, int64_t n, double* out);
 // scp_qp_get_solution + scp_kinematics + scp_check_avoidance + scp_select_pairs of a small problem in one launch
 int scp_select_from_solution(scp_ctx* ctx, int N, int K, int D, double R, double h, int64_t q_begin, int64_t q_end,

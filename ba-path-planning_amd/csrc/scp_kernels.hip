@@ -522,6 +522,10 @@ struct PairArgs {
   const double *p0, *v0;
   double* x_out;         // [N][K][D] copy of x_tm, and
   double* pos_out;       // [N][K][D] its positions (written by the first workgroup of every time step)
+  int64_t* spec_rows;    // violations from a solution: also the selection around the NEW positions (margin spec_margin) ->
+  int64_t spec_cap;      //   this list and
+  uint32_t* spec_bitmap; //   this bitmap (replaced); NULL: none
+  double spec_margin;
   const double* rel_prev;  // [N][K][D] or NULL: the tail also leaves the partial sums of scp_rel_step(x_tm, rel_prev) in the mirror
   int rel_blocks;
   unsigned long long* wg_part;  // [workgroups][4]: per-workgroup (min distance | max violation, first violation, marked rows, -)
@@ -618,11 +622,17 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
   const double* P = NEED_P ? a.P_tm + (int64_t)k * N * D : nullptr;
   const double* Q = NEED_Q ? a.Q_tm + (int64_t)k * N * D : nullptr;
   __shared__ uint32_t small_map_store[SMALL ? PAIR_ROWS / 32 : 1];
+  __shared__ uint32_t small_map2_store[SMALL && MODE == MODE_VIOL_RECOMPUTE ? PAIR_ROWS / 32 : 1];
   uint32_t* const small_map = small_map_store;
+  uint32_t* const small_map2 = small_map2_store;  // the speculative selection around the NEW positions (a.spec_rows)
+  const double* Pn = nullptr;                     // ... and those positions (third LDS slice)
   if (SMALL) {
     small_map[threadIdx.x] = 0u;  // (PAIR_ROWS / 32 == PAIR_THREADS words)
+    if (MODE == MODE_VIOL_RECOMPUTE) small_map2[threadIdx.x] = 0u;
     double* sP = lds;
     double* sQ = lds + (NEED_P ? (int64_t)N * D : 0);
+    double* sN = lds + 2 * (int64_t)N * D;
+    if (MODE == MODE_VIOL_RECOMPUTE && a.spec_rows) Pn = sN;
     const int C = N * D;
     for (int c = threadIdx.x; c < C; c += PAIR_THREADS) {
       const int i = c / D, d = c - i * D;
@@ -652,6 +662,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
           pn = a.pos_b[g];
         }
         sQ[c] = pn - pa;  // dP = P_new - P_prev (pair_prep_delta_kernel)
+        if (a.spec_rows) sN[c] = pn;
       }
     }
     __syncthreads();
@@ -810,6 +821,14 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
             const double viol = (a.R - dist) - qd;  // l_r - (A x)_r
             if (valid[u][e]) my_maxv = fmax(my_maxv, viol);
             sel[u][e] = valid[u][e] && (viol > a.margin) && !((marked[u] >> e) & 1u);
+            if (SMALL && Pn) {  // the selection test of MODE_SELECT around the new positions (the next linearisation point)
+              const PairGeom<D> g2 = pair_geom<D>(load_pt<D>(Pn, i), load_pt<D>(Pn, j));
+              const double dist2 = g2.deg ? 1.0 : g2.raw;
+              if (valid[u][e] && ((dist2 - a.R) < a.spec_margin)) {
+                const int o = 2 * (int)threadIdx.x + (s0 + u) * (2 * PAIR_THREADS) + e;
+                atomicOr(small_map2 + (o >> 5), 1u << (o & 31));
+              }
+            }
           }
         } else {
           const Pt<D> Qi = load_pt<D>(Q, i), Qj = load_pt<D>(Q, j);
@@ -896,14 +915,23 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
     __shared__ int last_sh;
     __shared__ int woff[SCP_SMALL_MAX_WG + 1];
     const unsigned n_wg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
-    // (a) this workgroup's marks -> its sorted sub-list (offsets within the workgroup's PAIR_ROWS rows)
-    int cnt_wg = 0;
+    constexpr bool SPEC = MODE == MODE_VIOL_RECOMPUTE;  // may carry a second, speculative selection (a.spec_rows)
+    const bool spec = SPEC && a.spec_rows != nullptr;
+    // (a) this workgroup's marks -> its sorted sub-list(s) (offsets within the workgroup's PAIR_ROWS rows)
+    int cnt_wg = 0, cnt2_wg = 0;
     if (MODE != MODE_CHECK) {
       const uint32_t w = small_map[threadIdx.x];
       int ex = block_exclusive_scan(__popc(w), &cnt_wg);
       uint32_t* sub = a.wg_rows + (size_t)wg * PAIR_ROWS;
       for (uint32_t m_ = w; m_; m_ &= m_ - 1)
         __hip_atomic_store(sub + ex++, 32u * threadIdx.x + (uint32_t)(__ffs((int)m_) - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (spec) {
+        const uint32_t w2 = small_map2[threadIdx.x];
+        int ex2 = block_exclusive_scan(__popc(w2), &cnt2_wg);
+        uint32_t* sub2 = a.wg_rows + ((size_t)n_wg + wg) * PAIR_ROWS;
+        for (uint32_t m_ = w2; m_; m_ &= m_ - 1)
+          __hip_atomic_store(sub2 + ex2++, 32u * threadIdx.x + (uint32_t)(__ffs((int)m_) - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     if (threadIdx.x == 0) {
       double m = red_d[0];
@@ -916,6 +944,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
       __hip_atomic_store(a.wg_part + 4 * wg, (unsigned long long)__double_as_longlong(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(a.wg_part + 4 * wg + 1, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(a.wg_part + 4 * wg + 2, (unsigned long long)cnt_wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.wg_part + 4 * wg + 3, (unsigned long long)cnt2_wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __threadfence();  // this thread's sub-list entries (and the partial) are visible device-wide ...
     __syncthreads();
@@ -924,27 +953,16 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
     if (!last_sh) return;
     __threadfence();
     // ---- (b) tail: the last workgroup alone.  Work ~ workgroups + marked rows, not ~ bitmap words ----
-    const bool merge = a.merge_into != nullptr;
-    if (MODE != MODE_CHECK && merge && a.overwrite)  // a new working set: the bitmap is rebuilt from nothing (atomics only:
-    {
-      for (int64_t w = threadIdx.x; w < a.words; w += PAIR_THREADS) atomicAnd(a.merge_into + w, 0u);  // same path as the ORs below)
-      __threadfence();  // (performed before any OR below is issued: barriers follow)
-    }
     const int G = (int)((n_wg + PAIR_THREADS - 1) / PAIR_THREADS);  // consecutive workgroups per thread (<= 8)
     double m = VIOL ? -INF : INF;
     unsigned long long f = 0xFFFFFFFFFFFFFFFFULL;
-    int cnt[SCP_SMALL_MAX_WG / PAIR_THREADS], mine = 0;
-#pragma unroll
-    for (int e = 0; e < SCP_SMALL_MAX_WG / PAIR_THREADS; ++e) {
+    for (int e = 0; e < G; ++e) {
       const unsigned w = threadIdx.x * G + e;
-      cnt[e] = 0;
-      if (e < G && w < n_wg) {
+      if (w < n_wg) {
         const double pm = __longlong_as_double((long long)__hip_atomic_load(a.wg_part + 4 * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         const unsigned long long pf = __hip_atomic_load(a.wg_part + 4 * w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cnt[e] = (int)__hip_atomic_load(a.wg_part + 4 * w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         m = VIOL ? fmax(m, pm) : fmin(m, pm);
         f = pf < f ? pf : f;
-        mine += cnt[e];
       }
     }
     m = VIOL ? wave_max(m) : wave_min(m);
@@ -953,18 +971,31 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
       red_d[threadIdx.x >> 6] = m;
       red_u[threadIdx.x >> 6] = f;
     }
-    int total = 0;
-    int run = block_exclusive_scan(mine, &total);  // (its barriers also order red_d / red_u and the bitmap clearing)
+    // one list: the sub-lists `which` of all workgroups, concatenated in workgroup (= row) order -> rows_out; their bits are
+    // merged into (all or nothing: a list that is too short is repeated) or replace (overwrite) the bitmap bm
+    auto emit = [&](int which, int64_t* rows_out, int64_t cap_out, uint32_t* bm, bool overwrite_) -> int {
+      if (bm && overwrite_) {  // a new working set: the bitmap is rebuilt from nothing (atomics only: the path of the ORs below)
+        for (int64_t w = threadIdx.x; w < a.words; w += PAIR_THREADS) atomicAnd(bm + w, 0u);
+        __threadfence();  // (performed before any OR below is issued: barriers follow)
+      }
+      int cnt[SCP_SMALL_MAX_WG / PAIR_THREADS], mine = 0;
 #pragma unroll
-    for (int e = 0; e < SCP_SMALL_MAX_WG / PAIR_THREADS; ++e) {
-      const unsigned w = threadIdx.x * G + e;
-      if (e < G && w < n_wg) woff[w] = run;
-      run += cnt[e];
-    }
-    if (threadIdx.x == 0) woff[n_wg] = total;
-    __syncthreads();
-    if (MODE != MODE_CHECK) {
-      const bool overflow = merge && !a.overwrite && (int64_t)total > a.cap;  // (a merging pass merges all or nothing)
+      for (int e = 0; e < SCP_SMALL_MAX_WG / PAIR_THREADS; ++e) {
+        const unsigned w = threadIdx.x * G + e;
+        cnt[e] = (e < G && w < n_wg) ? (int)__hip_atomic_load(a.wg_part + 4 * w + 2 + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        mine += cnt[e];
+      }
+      int total = 0;
+      int run = block_exclusive_scan(mine, &total);  // (its barriers also order woff of an earlier list and red_d / red_u)
+#pragma unroll
+      for (int e = 0; e < SCP_SMALL_MAX_WG / PAIR_THREADS; ++e) {
+        const unsigned w = threadIdx.x * G + e;
+        if (e < G && w < n_wg) woff[w] = run;
+        run += cnt[e];
+      }
+      if (threadIdx.x == 0) woff[n_wg] = total;
+      __syncthreads();
+      const bool overflow = bm != nullptr && !overwrite_ && (int64_t)total > cap_out;
       for (int sl = threadIdx.x; sl < total; sl += PAIR_THREADS) {
         int lo = 0, hi = (int)n_wg;  // the workgroup whose sub-list holds slot sl: the last g with woff[g] <= sl
         while (hi - lo > 1) {
@@ -972,16 +1003,26 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
           if (woff[mid] <= sl) lo = mid;
           else hi = mid;
         }
-        const uint32_t o = __hip_atomic_load(a.wg_rows + (size_t)lo * PAIR_ROWS + (sl - woff[lo]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t o = __hip_atomic_load(a.wg_rows + ((size_t)which * n_wg + lo) * PAIR_ROWS + (sl - woff[lo]), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
         const int64_t kg = lo / (int)gridDim.x, xg = lo % (int)gridDim.x;
         const int64_t q_loc = xg * PAIR_ROWS - ((kg * nq) & 1) + (int64_t)o;  // pair offset within [q_begin, q_end)
-        if (!overflow && sl < a.cap) a.rows[sl] = kg * a.pairs + a.q_begin + q_loc;
-        if (merge && !overflow) {
+        if (!overflow && sl < cap_out) rows_out[sl] = kg * a.pairs + a.q_begin + q_loc;
+        if (bm && !overflow) {
           const int64_t lr = kg * nq + q_loc;
-          atomicOr(a.merge_into + (lr >> 5), 1u << (lr & 31));
+          atomicOr(bm + (lr >> 5), 1u << (lr & 31));
         }
       }
-    }
+      __syncthreads();  // (woff is free again)
+      return total;
+    };
+    int total = 0, total2 = 0;
+    if (MODE != MODE_CHECK) total = emit(0, a.rows, a.cap, a.merge_into, a.overwrite != 0);
+    else __syncthreads();
+    if (spec) total2 = emit(1, a.spec_rows, a.spec_cap, a.spec_bitmap, true);
+    if (SPEC && a.mirror && threadIdx.x == 0)
+      __hip_atomic_store((unsigned long long*)&a.mirror->n_spec, (unsigned long long)(spec ? total2 : 0), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
     if (MODE == MODE_VIOL_RECOMPUTE && a.rel_prev && a.mirror) {  // rel_step_partial_kernel, block after block
       __shared__ double rs0[PAIR_THREADS / 64], rs1[PAIR_THREADS / 64];
       const int64_t n = (int64_t)N * a.K * D, C = (int64_t)N * D;
@@ -1156,12 +1197,13 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
   if (tail) tail->done = false;
   if constexpr (MODE == MODE_SELECT || MODE == MODE_VIOL_RECOMPUTE || MODE == MODE_CHECK)
   if (tail) {
-    const size_t lds_small = (size_t)(MODE == MODE_VIOL_RECOMPUTE ? 2 : 1) * N * D * sizeof(double);
-    if (small_pass_ok(ctx, N, K, D, nq, MODE == MODE_VIOL_RECOMPUTE ? 2 : 1)) {
+    const int n_slices = MODE == MODE_VIOL_RECOMPUTE ? (a.spec_rows ? 3 : 2) : 1;
+    const size_t lds_small = (size_t)n_slices * N * D * sizeof(double);
+    if (small_pass_ok(ctx, N, K, D, nq, n_slices)) {
       a.pos_a = pos_ref_layout;
       if (MODE == MODE_VIOL_RECOMPUTE && !a.x_tm) a.pos_b = p0;
       if (MODE != MODE_CHECK) {  // per-workgroup sub-lists of the marked rows (grown on demand, owned by the ctx)
-        const size_t need = (size_t)scp_cdiv(nq + 1, PAIR_ROWS) * K * PAIR_ROWS * sizeof(uint32_t);
+        const size_t need = (size_t)(a.spec_rows ? 2 : 1) * scp_cdiv(nq + 1, PAIR_ROWS) * K * PAIR_ROWS * sizeof(uint32_t);
         if (ctx->wg_rows_bytes < need) {
           if (ctx->wg_rows) {
             SCP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1713,13 +1755,14 @@ extern "C" int scp_collision_violations_at(scp_ctx* ctx, int N, int K, int D, do
 int scp_violations_from_solution(scp_ctx* ctx, int N, int K, int D, double R, double h, int64_t q_begin, int64_t q_end,
                                  const double* pos_prev, const double* x_tm, const double* p0, const double* v0, double* x_out,
                                  double* pos_out, double feas_tol, int64_t* new_rows, int64_t new_cap, uint32_t* sel_bitmap,
-                                 scp_pair_stats* stats, const double* rel_prev, double* rel_out, bool* fused) {
-  (void)rel_out;
+                                 scp_pair_stats* stats, const double* rel_prev, int64_t* spec_rows, int64_t spec_cap,
+                                 uint32_t* spec_bitmap, double spec_margin, bool* fused) {
   *fused = false;
   int rc = check_pair_range(ctx, N, K, D, q_begin, q_end);
   if (rc) return rc;
   const int64_t nq = q_end - q_begin;
   if (!small_pass_ok(ctx, N, K, D, nq, 2)) return SCP_OK;
+  if (!spec_bitmap || !small_pass_ok(ctx, N, K, D, nq, 3)) spec_rows = nullptr;  // (no LDS for the third slice: no speculation)
   PairArgs a{};
   a.N = N; a.K = K; a.D = D; a.R = R; a.h = h;
   a.q_begin = q_begin; a.q_end = q_end; a.pairs = scp_pairs(N);
@@ -1732,6 +1775,7 @@ int scp_violations_from_solution(scp_ctx* ctx, int N, int K, int D, double R, do
   a.x_tm = x_tm; a.p0 = p0; a.v0 = v0; a.x_out = x_out; a.pos_out = pos_out;
   a.rel_prev = rel_prev;
   a.rel_blocks = rel_step_blocks((int64_t)N * K * D);
+  a.spec_rows = spec_rows; a.spec_cap = spec_cap; a.spec_bitmap = spec_bitmap; a.spec_margin = spec_margin;
   PassTail tail{new_rows, new_cap, sel_bitmap, false, words, false};
   rc = launch_pair_pass<MODE_VIOL_RECOMPUTE>(ctx, a, pos_prev, nullptr, nullptr, nullptr, 0, &tail);
   if (rc) return rc;

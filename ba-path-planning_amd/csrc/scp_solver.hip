@@ -37,6 +37,8 @@ struct StepState {
   bool fuse_ok;           // all phases run inside one call (solve_joint_qp): a round's solution may stay in the QP's layout
   bool solution_pending;  // ... until the violations pass derives x and its positions itself (small problems)
   bool rel_ready;         // that pass also left scp_rel_step(x, acc_in) behind: rel[]
+  bool spec_ok;           // ... and the selection around the new positions in s->sel2 / s->bitmap2 (spec_n rows)
+  int64_t spec_n;
   double rel[3];
   double t0;            // wall clock at the start of the step
   double lim_copy[6], space_copy[6];  // sharded steps: the host arrays outlive the call that passed them
@@ -67,6 +69,10 @@ struct scp_solver {
   bool spec_valid;
   int64_t spec_n;
   double spec_margin;
+  bool want_spec;       // scp_solver_solve is running: a next linearisation may follow the current one
+  int64_t* sel2;        // the speculative selection's list and bitmap (allocated on first use, swapped in when accepted)
+  int64_t sel2_cap;
+  uint32_t* bitmap2;
   double rho_start;  // > 0: the joint QP of the next step starts at this rho (options.carry_rho), else at settings.rho
   struct StepState* step;  // the SCP iteration in flight (phases of solve_joint_qp / of the sharded entry points)
 };
@@ -286,14 +292,24 @@ int step_violations(scp_solver* s, StepState& t, int64_t* n_new) {
   for (;;) {
     if (t.solution_pending) {
       bool fused = false;
+      const bool spec = s->want_spec && t.row_free && t.q_begin == 0 && t.q_end == s->pairs;
+      if (spec && !s->sel2) {  // (first use: the second list / bitmap of the speculative selection)
+        const size_t words = (size_t)std::max<int64_t>((s->rows + 31) / 32, 1);
+        SV_HIP(hipMalloc(&s->sel2, (size_t)s->sel_cap * sizeof(int64_t)));
+        s->sel2_cap = s->sel_cap;
+        SV_HIP(hipMalloc(&s->bitmap2, words * sizeof(uint32_t)));
+      }
       SV_CHECK(scp_violations_from_solution(ctx, s->N, s->K, s->D, s->R, s->h, t.q_begin, t.q_end, s->pos_a,
                                             scp_qp_solution_tm(s->qp), t.p0, t.v0, s->x, s->pos_b, t.o.feasibility_tol,
-                                            s->sel, s->sel_cap, s->bitmap, s->stats, t.acc_in, t.rel, &fused));
+                                            s->sel, s->sel_cap, s->bitmap, s->stats, t.acc_in, spec ? s->sel2 : nullptr,
+                                            s->sel2_cap, s->bitmap2, t.o.working_set_margin, &fused));
       t.solution_pending = false;  // (s->x and s->pos_b exist from here on, also for a repeat with a longer list)
       if (fused) {
         SV_CHECK(read_stats(s, true));
         scp_ctx_mirror_rel(ctx, (int64_t)s->N * s->K * s->D, t.rel);
         t.rel_ready = true;
+        t.spec_n = (int64_t)ctx->h_mirror->n_spec;
+        t.spec_ok = spec && t.spec_n > 0 && t.spec_n <= s->sel2_cap;
         if ((int64_t)s->h_stats->n_selected <= s->sel_cap) break;
         SV_CHECK(grow_sel(s, (int64_t)s->h_stats->n_selected));
         continue;
@@ -386,7 +402,7 @@ extern "C" void scp_solver_destroy(scp_solver* s) {
   if (!s) return;
   (void)hipStreamSynchronize(s->ctx->stream);
   if (s->qp) scp_qp_destroy(s->qp);
-  void* dev[] = {s->eta, s->bitmap, s->sel, s->stats, s->ws, s->acc, s->x, s->pos_a, s->pos_b, s->vel};  // (l lives in eta's allocation)
+  void* dev[] = {s->eta, s->bitmap, s->sel, s->bitmap2, s->sel2, s->stats, s->ws, s->acc, s->x, s->pos_a, s->pos_b, s->vel};  // (l lives in eta's allocation)
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (s->h_stats) (void)hipHostFree(s->h_stats);
@@ -457,6 +473,7 @@ extern "C" int scp_solver_solve(scp_solver* s, const double* limits, const doubl
   res->first_violation = UINT64_MAX;
   const double t_start = now_s();
   s->spec_valid = false;
+  s->want_spec = true;
 
   // a2 + a3: bounds, QP#0 (scp.py:137-138, :323-369)
   SV_CHECK(scp_qp_set_problem(s->qp, limits, space, p0, v0, pf, vf));
@@ -542,6 +559,14 @@ extern "C" int scp_solver_solve(scp_solver* s, const double* limits, const doubl
     std::swap(s->pos_a, s->pos_b);
     acc = s->acc;
     ++iteration;
+    if (s->step->spec_ok) {  // the round's last pass also selected around these positions: the next linearisation is done
+      std::swap(s->sel, s->sel2);
+      std::swap(s->sel_cap, s->sel2_cap);
+      std::swap(s->bitmap, s->bitmap2);
+      s->spec_valid = true;
+      s->spec_n = s->step->spec_n;
+      s->spec_margin = o->working_set_margin;
+    }
     if (o->refresh_feasibility && !converged) {  // opt-in (the reference leaves a TODO, scp.py:150)
       SV_CHECK(scp_check_avoidance(ctx, N, K, D, s->R, 0, s->pairs, s->pos_a, s->stats));
       SV_CHECK(read_stats(s, false));
@@ -549,6 +574,7 @@ extern "C" int scp_solver_solve(scp_solver* s, const double* limits, const doubl
     }
   }
   s->rho_start = 0.0;  // (the polish QP and later solves start at settings.rho)
+  s->want_spec = false;  // (no linearisation follows the polish QP's)
   res->n_iterations = iteration;
   res->converged = converged ? 1 : 0;
   res->feasible_at_exit = is_feasible ? 1 : 0;
@@ -582,6 +608,7 @@ extern "C" int scp_solver_step(scp_solver* s, const double* limits, const double
   const double t0 = now_s();
   s->rho_start = 0.0;
   s->spec_valid = false;
+  s->want_spec = false;
   SV_CHECK(scp_qp_set_problem(s->qp, limits, space, p0, v0, pf, vf));
   SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, acc_in, p0, v0, s->pos_a, nullptr));
   SV_CHECK(solve_joint_qp(s, acc_in, limits, space, p0, v0, pf, vf, o, 0.0, rec));
@@ -622,6 +649,7 @@ extern "C" int scp_solver_shard_begin(scp_solver* s, const double* limits, const
   step_restore(s, t);
   s->rho_start = 0.0;
   s->spec_valid = false;
+  s->want_spec = false;
   double lim[6], spc[6];
   memcpy(lim, limits, sizeof(lim));
   memcpy(spc, space, 2 * D * sizeof(double));

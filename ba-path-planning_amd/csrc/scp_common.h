@@ -107,6 +107,8 @@ int scp_select_from_solution(scp_ctx* ctx, int N, int K, int D, double R, double
                              const double* x_tm, const double* p0, const double* v0, double* x_out, double* pos_out,
                              double margin, int64_t* sel_rows, int64_t sel_cap, uint32_t* sel_bitmap, scp_pair_stats* stats,
                              bool* fused);
+int scp_launch_kinematics_copy(scp_ctx* ctx, int N, int K, int D, double h, const double* acc, const double* p0,
+                               const double* v0, double* pos_out, double* vel_out, double* acc_copy);
 // the QP's current iterate in its own layout ([K][N D], device pointer)
 const double* scp_qp_solution_tm(const scp_qp* qp);
 

@@ -254,9 +254,10 @@ __global__ __launch_bounds__(256) void kinematics_kernel(int N, int K, int D, do
                                                           const double* __restrict__ acc,
                                                           const double* __restrict__ p0,
                                                           const double* __restrict__ v0, double* __restrict__ pos,
-                                                          double* __restrict__ vel) {
+                                                          double* __restrict__ vel, double* __restrict__ acc_copy) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= (int64_t)N * K * D) return;
+  if (acc_copy) acc_copy[t] = acc[t];  // (the solver's final launch also hands the accelerations out: no copy launch)
   const int d = (int)(t % D);
   const int k = (int)((t / D) % K);
   const int i = (int)(t / ((int64_t)D * K));
@@ -273,7 +274,17 @@ extern "C" int scp_kinematics(scp_ctx* ctx, int N, int K, int D, double h, const
   SCP_REQUIRE(ctx, acc && p0 && v0 && pos_out, "kinematics: null pointer");
   const int64_t n = (int64_t)N * K * D;
   hipLaunchKernelGGL(kinematics_kernel, dim3(scp_cdiv(n, 256)), dim3(256), 0, ctx->stream, N, K, D, h, acc, p0,
-                     v0, pos_out, vel_out);
+                     v0, pos_out, vel_out, (double*)nullptr);
+  SCP_HIP_CHECK(ctx, hipGetLastError());
+  return SCP_OK;
+}
+
+// scp_kinematics + a copy of `acc` to acc_copy in the same launch (scp_common.h)
+int scp_launch_kinematics_copy(scp_ctx* ctx, int N, int K, int D, double h, const double* acc, const double* p0,
+                               const double* v0, double* pos_out, double* vel_out, double* acc_copy) {
+  const int64_t n = (int64_t)N * K * D;
+  hipLaunchKernelGGL(kinematics_kernel, dim3(scp_cdiv(n, 256)), dim3(256), 0, ctx->stream, N, K, D, h, acc, p0,
+                     v0, pos_out, vel_out, acc_copy);
   SCP_HIP_CHECK(ctx, hipGetLastError());
   return SCP_OK;
 }
@@ -1433,7 +1444,6 @@ __global__ __launch_bounds__(CMP_THREADS) void compact_write_kernel(uint32_t* __
 // Small maps (up to CMP1_MAX_WORDS words = 2 M rows, e.g. every map of a 128-agent problem): count, scan, write and the
 // stats mirror in ONE workgroup -- the three-launch version costs more in launch boundaries than in work there.
 constexpr int CMP1_THREADS = 1024;
-constexpr int CMP1_WORDS = CMP1_THREADS * CMP_WPT;
 
 // The body, for THREADS threads of ONE workgroup (all of them must call it): returns the number of set bits.
 // OVERWRITE: merge_into := map (every word, also the empty ones: the working-set bitmap of a NEW linearisation, no clearing

@@ -1782,7 +1782,9 @@ __global__ __launch_bounds__(FT) void cg1_resid_col_kernel(int K, int Rf, int64_
                                                             const double* __restrict__ coef,
                                                             const double* __restrict__ gval,
                                                             const double* __restrict__ gval2, double* __restrict__ Qx,
-                                                            double* __restrict__ Fx, double* __restrict__ part) {
+                                                            double* __restrict__ Fx, double* __restrict__ part,
+                                                            unsigned* __restrict__ ticket, unsigned long long* flag,
+                                                            unsigned long long seq) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int RSF = pad_col(Rf), RSK = pad_col(K);
   double* YF = lds;              // [16][RSF]  y_f, then delta-y_f, then F x (a column is only touched by its own wave)
@@ -1913,6 +1915,14 @@ __global__ __launch_bounds__(FT) void cg1_resid_col_kernel(int K, int Rf, int64_
     part[(size_t)blockIdx.x * SCP_RESID_STRIDE + j] = t;
   }
   PHASE_MARK(38);
+  if (flag) {  // no row kernel follows (QP#0): the LAST workgroup raises the host's completion word itself -- one launch less
+    if (threadIdx.x < 9) __threadfence_system();  // (the partials live in mapped host memory)
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
+      *ticket = 0u;  // (the next launch on this stream starts after this kernel has ended)
+      __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 constexpr int RESID_ROW_BLOCKS = 128;
@@ -1986,16 +1996,21 @@ int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
                        d.yc, (const double*)nullptr, d.pos_i, d.pos_j, d.gval2, with_dy ? d.dyc : (const double*)nullptr,
                        with_dy ? d.gval3 : (double*)nullptr);
   const size_t lds = (size_t)CB * (pad_col(Rf) + 4 * pad_col(K)) * sizeof(double);
+  const unsigned long long seq = ++qp->check_seq;
+  unsigned long long* flag_dev = (unsigned long long*)(qp->h_scal_dev + SL_COUNT + SCP_RESID_CAP);
+  unsigned* ticket = ctx->d_ticket + 1;  // ([0]: the small-problem pairwise passes; same stream, never concurrent)
   if (K <= 64) {
     int rc = allow_lds(qp, cg1_resid_col_kernel<1>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(cg1_resid_col_kernel<1>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->h, qp->N, qp->D, with_dy ? 1 : 0,
-                       has_rows, d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval2, d.gval3, Qx, d.fx, part);
+                       has_rows, d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval2, d.gval3, Qx, d.fx, part,
+                       ticket, has_rows ? nullptr : flag_dev, seq);
   } else {
     int rc = allow_lds(qp, cg1_resid_col_kernel<2>, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(cg1_resid_col_kernel<2>, dim3(nblk), dim3(FT), lds, s, K, Rf, C, qp->h, qp->N, qp->D, with_dy ? 1 : 0,
-                       has_rows, d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval2, d.gval3, Qx, d.fx, part);
+                       has_rows, d.x, d.zf, d.yf, d.lf, d.uf, d.dyf, d.cell_ptr, d.coef, d.gval2, d.gval3, Qx, d.fx, part,
+                       ticket, has_rows ? nullptr : flag_dev, seq);
   }
   double* rpart = part + (size_t)nblk * SCP_RESID_STRIDE;
   if (!has_rows) {
@@ -2009,10 +2024,10 @@ int scp_qp_fused_residuals(scp_qp* qp, bool with_dy) {
   FUSED_LAUNCHED(qp);
   const int npart = nblk + (has_rows ? RESID_ROW_BLOCKS : 0);
   volatile unsigned long long* flag = (volatile unsigned long long*)(qp->h_scal + SL_COUNT + SCP_RESID_CAP);
-  const unsigned long long seq = ++qp->check_seq;
-  hipLaunchKernelGGL(check_done_kernel, dim3(1), dim3(1), 0, s, (unsigned long long*)(qp->h_scal_dev + SL_COUNT + SCP_RESID_CAP),
-                     seq);
-  FUSED_LAUNCHED(qp);
+  if (has_rows) {
+    hipLaunchKernelGGL(check_done_kernel, dim3(1), dim3(1), 0, s, flag_dev, seq);
+    FUSED_LAUNCHED(qp);
+  }
   {
     if (!scp_wait_host_word(flag, seq, 20)) SCP_HIP_CHECK(ctx, hipStreamSynchronize(s));  // a fault surfaces here
     if (*flag != seq) return scp_fail(ctx, SCP_ERR_HIP, "fused check: completion flag not written");

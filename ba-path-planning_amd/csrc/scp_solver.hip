@@ -468,7 +468,6 @@ extern "C" int scp_solver_solve(scp_solver* s, const double* limits, const doubl
               "solver_solve: null pointer");
   SCP_REQUIRE(ctx, record_capacity >= o->max_iterations + 2, "solver_solve: %d records needed", o->max_iterations + 2);
   const int N = s->N, K = s->K, D = s->D;
-  const size_t nbytes = (size_t)N * K * D * sizeof(double);
   memset(res, 0, sizeof(*res));
   res->first_violation = UINT64_MAX;
   const double t_start = now_s();
@@ -590,8 +589,7 @@ extern "C" int scp_solver_solve(scp_solver* s, const double* limits, const doubl
     std::swap(s->pos_a, s->pos_b);
   }
   // final kinematics (scp.py:169)
-  SV_CHECK(scp_kinematics(ctx, N, K, D, s->h, s->acc, p0, v0, pos_out, vel_out));
-  SV_HIP(hipMemcpyAsync(acc_out, s->acc, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+  SV_CHECK(scp_launch_kinematics_copy(ctx, N, K, D, s->h, s->acc, p0, v0, pos_out, vel_out, acc_out));
   SV_HIP(hipStreamSynchronize(ctx->stream));
   res->time_sec = now_s() - t_start;
   return SCP_OK;

@@ -237,14 +237,23 @@ __device__ inline void kin_point(const double* __restrict__ a, int64_t stride, i
   const double hkv = hk * vi;
   double p = pi + hkv;  // p0 + (h*k)*v0   scp.py:393
   const double hh = h * h;
-#pragma unroll 8  // (eight loads in flight; the sum stays in the reference's order)
-  for (int j = 0; j < k; ++j) {
-    const double aj = a[(int64_t)j * stride];
-    const double hv = h * aj;
-    v = v + hv;  // scp.py:390
-    const double w = hh * ((double)(k - j) - 0.5);
-    const double wa = w * aj;
-    p = p + wa;  // scp.py:395
+  constexpr int KIN_CHUNK = 32;  // loads in flight per pass; the sums stay in the reference's order
+  for (int j0 = 0; j0 < k; j0 += KIN_CHUNK) {
+    double av[KIN_CHUNK];
+#pragma unroll
+    for (int u = 0; u < KIN_CHUNK; ++u) av[u] = j0 + u < k ? a[(int64_t)(j0 + u) * stride] : 0.0;
+#pragma unroll
+    for (int u = 0; u < KIN_CHUNK; ++u) {
+      if (j0 + u < k) {
+        const int j = j0 + u;
+        const double aj = av[u];
+        const double hv = h * aj;
+        v = v + hv;  // scp.py:390
+        const double w = hh * ((double)(k - j) - 0.5);
+        const double wa = w * aj;
+        p = p + wa;  // scp.py:395
+      }
+    }
   }
   p_out = p;
   v_out = v;
@@ -500,6 +509,8 @@ struct PairUnroll {
   static constexpr int value = (USE_LDS && MODE != 2 /* MODE_VIOLATIONS: streaming reads, 4 in flight */) ? 2 : 4;
 };
 constexpr int PAIR_ROWS = PAIR_THREADS * PAIR_STEPS * 2;   // rows (= pairs at one k) per workgroup
+constexpr int SMALL_STEPS = 4;                             // ... of a small-problem pass: 2048 rows per workgroup, so that a
+constexpr int SMALL_ROWS = PAIR_THREADS * SMALL_STEPS * 2; // 128-agent problem still spreads over 200 compute units
 constexpr int64_t CMP1_MAX_WORDS = 64 * 1024;             // bitmap words (2 M rows) one workgroup compacts (compact_small_body)
 
 enum PairMode { MODE_LINEARIZE = 0, MODE_CHECK = 1, MODE_VIOLATIONS = 2, MODE_VIOL_RECOMPUTE = 3, MODE_SELECT = 4 };
@@ -540,7 +551,7 @@ struct PairArgs {
   const double* rel_prev;  // [N][K][D] or NULL: the tail also leaves the partial sums of scp_rel_step(x_tm, rel_prev) in the mirror
   int rel_blocks;
   unsigned long long* wg_part;  // [workgroups][4]: per-workgroup (min distance | max violation, first violation, marked rows, -)
-  uint32_t* wg_rows;     // [workgroups][PAIR_ROWS]: per-workgroup sorted sub-lists of the marked rows (offsets within the workgroup)
+  uint32_t* wg_rows;     // [workgroups][SMALL_ROWS]: per-workgroup sorted sub-lists of the marked rows (offsets within the workgroup)
   unsigned* ticket;      // last-workgroup-done counter (self-resetting)
   int64_t* rows;         // tail: the sorted list of the marked rows, capacity `cap`
   int64_t cap;
@@ -603,9 +614,26 @@ __device__ inline void pair_advance_far(int& i, int& j, int N, int s, int64_t q_
 // pairwise kernel spent -> the clock the kernel actually ran at (MI355X_MICROARCH.md, in-kernel clock check)
 constexpr int SCP_PAIR_CLK_WGS = 4096;
 __device__ unsigned long long scp_pair_clk[2 * SCP_PAIR_CLK_WGS];
+// ... and the 100 MHz stamps of the LAST workgroup of a small-problem pass (thread 0), phase by phase (tools/small_pass_profile.py)
+__device__ unsigned long long scp_small_clk[16];
+#define SMALL_STAMP(i) do { if (threadIdx.x == 0) small_clk_local[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SMALL_STAMP(i) do { } while (0)
 #endif
 
 __device__ inline int block_exclusive_scan(int v, int* total);  // (256 threads; defined with the compaction kernels below)
+
+// Data one workgroup of a small-problem pass hands to the LAST workgroup of the same kernel (possibly on another XCD, behind
+// another L2): written through to the device's coherence point and read past the local L2.  With every such store written
+// through, "my stores have been performed" is a wait for their acknowledgements -- no L2 write-back (a __threadfence() per
+// workgroup walks the L2 each time: 9 us at 200 workgroups).
+__device__ inline void store_coherent(double* p, double v) {
+  __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline double load_coherent(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ inline void wait_stores_performed() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
 // SMALL (problems whose bitmap one workgroup compacts: <= 2 M rows, e.g. 128 agents x 50 steps): the pass is ONE launch.
 // Every workgroup stages its time step straight from the [N][K][D] arrays (no prep kernel) -- the violations pass can even
@@ -620,26 +648,34 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
   const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
   extern __shared__ __attribute__((aligned(16))) double lds[];
+#ifdef SCP_PHASE_PROFILE
+  unsigned long long small_clk_local[16] = {};
+  SMALL_STAMP(0);
+#endif
   const int N = a.N;
   const int k = blockIdx.y;
   const int64_t nq = a.q_end - a.q_begin;
   const int64_t slice0 = (int64_t)k * nq;       // first local row of this k
   const int64_t par = slice0 & 1;               // keep every thread's first row at an even local row id
-  const int64_t c0 = (int64_t)blockIdx.x * PAIR_ROWS - par;  // first local pair offset of this workgroup
+  constexpr int STEPS = SMALL ? SMALL_STEPS : PAIR_STEPS;
+  constexpr int ROWS = PAIR_THREADS * STEPS * 2;
+  const int64_t c0 = (int64_t)blockIdx.x * ROWS - par;  // first local pair offset of this workgroup
   constexpr bool NEED_P = MODE != MODE_VIOLATIONS;
   constexpr bool NEED_Q = MODE != MODE_CHECK && MODE != MODE_SELECT;
   constexpr bool VIOL = MODE == MODE_VIOLATIONS || MODE == MODE_VIOL_RECOMPUTE;  // selects violated rows, reduces max violation
 
   const double* P = NEED_P ? a.P_tm + (int64_t)k * N * D : nullptr;
   const double* Q = NEED_Q ? a.Q_tm + (int64_t)k * N * D : nullptr;
-  __shared__ uint32_t small_map_store[SMALL ? PAIR_ROWS / 32 : 1];
-  __shared__ uint32_t small_map2_store[SMALL && MODE == MODE_VIOL_RECOMPUTE ? PAIR_ROWS / 32 : 1];
+  __shared__ uint32_t small_map_store[SMALL ? SMALL_ROWS / 32 : 1];
+  __shared__ uint32_t small_map2_store[SMALL && MODE == MODE_VIOL_RECOMPUTE ? SMALL_ROWS / 32 : 1];
   uint32_t* const small_map = small_map_store;
   uint32_t* const small_map2 = small_map2_store;  // the speculative selection around the NEW positions (a.spec_rows)
   const double* Pn = nullptr;                     // ... and those positions (third LDS slice)
   if (SMALL) {
-    small_map[threadIdx.x] = 0u;  // (PAIR_ROWS / 32 == PAIR_THREADS words)
-    if (MODE == MODE_VIOL_RECOMPUTE) small_map2[threadIdx.x] = 0u;
+    if (threadIdx.x < SMALL_ROWS / 32) {
+      small_map[threadIdx.x] = 0u;
+      if (MODE == MODE_VIOL_RECOMPUTE) small_map2[threadIdx.x] = 0u;
+    }
     double* sP = lds;
     double* sQ = lds + (NEED_P ? (int64_t)N * D : 0);
     double* sN = lds + 2 * (int64_t)N * D;
@@ -652,8 +688,8 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
         double pn, vn;
         kin_point(a.x_tm + c, C, k, a.h, a.p0[c], a.v0[c], pn, vn);
         if (blockIdx.x == 0) {
-          a.pos_out[g] = pn;
-          a.x_out[g] = a.x_tm[(int64_t)k * C + c];
+          store_coherent(a.pos_out + g, pn);
+          store_coherent(a.x_out + g, a.x_tm[(int64_t)k * C + c]);
         }
         sP[c] = pn;
         continue;
@@ -666,8 +702,8 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
           double vn;
           kin_point(a.x_tm + c, C, k, a.h, a.p0[c], a.v0[c], pn, vn);
           if (blockIdx.x == 0) {
-            a.pos_out[g] = pn;
-            a.x_out[g] = a.x_tm[(int64_t)k * C + c];
+            store_coherent(a.pos_out + g, pn);
+            store_coherent(a.x_out + g, a.x_tm[(int64_t)k * C + c]);
           }
         } else {
           pn = a.pos_b[g];
@@ -677,6 +713,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
       }
     }
     __syncthreads();
+    SMALL_STAMP(1);
     P = sP;
     Q = sQ;
   } else if (USE_LDS) {
@@ -715,14 +752,14 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
 
   // Interior workgroups (all PAIR_ROWS rows inside the slice: all but the first and last of a time step) take the
   // FULL instantiation, which carries no per-row validity masks, index clamps or scalar-store fallbacks.
-  const bool full = c0 >= 0 && c0 + PAIR_ROWS <= nq;
+  const bool full = c0 >= 0 && c0 + ROWS <= nq;
   double* const eta_k = a.eta + slice0;  // wave-uniform bases + 32-bit lane offsets: saddr-form global accesses
   double* const l_k = a.l + slice0;
   const int o0 = (int)off0;
   auto body = [&](auto full_tag) {
   constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll 1
-  for (int s0 = 0; s0 < PAIR_STEPS; s0 += PAIR_UNROLL) {
+  for (int s0 = 0; s0 < STEPS; s0 += PAIR_UNROLL) {
     double eta_v[PAIR_UNROLL][2][D];
     double l_v[PAIR_UNROLL][2];
     bool valid[PAIR_UNROLL][2];
@@ -890,7 +927,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           if (sel[u][e]) {
-            if (SMALL) {  // (this workgroup's own PAIR_ROWS-bit map in LDS: compacted below, no global bitmap)
+            if (SMALL) {  // (this workgroup's own SMALL_ROWS-bit map in LDS: compacted below, no global bitmap)
               const int o = 2 * (int)threadIdx.x + (s0 + u) * (2 * PAIR_THREADS) + e;
               atomicOr(small_map + (o >> 5), 1u << (o & 31));
             } else {
@@ -923,23 +960,24 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
   }
   __syncthreads();
   if constexpr (SMALL) {
+    SMALL_STAMP(2);
     __shared__ int last_sh;
     __shared__ int woff[SCP_SMALL_MAX_WG + 1];
     const unsigned n_wg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
     constexpr bool SPEC = MODE == MODE_VIOL_RECOMPUTE;  // may carry a second, speculative selection (a.spec_rows)
     const bool spec = SPEC && a.spec_rows != nullptr;
-    // (a) this workgroup's marks -> its sorted sub-list(s) (offsets within the workgroup's PAIR_ROWS rows)
+    // (a) this workgroup's marks -> its sorted sub-list(s) (offsets within the workgroup's SMALL_ROWS rows)
     int cnt_wg = 0, cnt2_wg = 0;
     if (MODE != MODE_CHECK) {
-      const uint32_t w = small_map[threadIdx.x];
+      const uint32_t w = threadIdx.x < SMALL_ROWS / 32 ? small_map[threadIdx.x] : 0u;
       int ex = block_exclusive_scan(__popc(w), &cnt_wg);
-      uint32_t* sub = a.wg_rows + (size_t)wg * PAIR_ROWS;
+      uint32_t* sub = a.wg_rows + (size_t)wg * SMALL_ROWS;
       for (uint32_t m_ = w; m_; m_ &= m_ - 1)
         __hip_atomic_store(sub + ex++, 32u * threadIdx.x + (uint32_t)(__ffs((int)m_) - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (spec) {
-        const uint32_t w2 = small_map2[threadIdx.x];
+        const uint32_t w2 = threadIdx.x < SMALL_ROWS / 32 ? small_map2[threadIdx.x] : 0u;
         int ex2 = block_exclusive_scan(__popc(w2), &cnt2_wg);
-        uint32_t* sub2 = a.wg_rows + ((size_t)n_wg + wg) * PAIR_ROWS;
+        uint32_t* sub2 = a.wg_rows + ((size_t)n_wg + wg) * SMALL_ROWS;
         for (uint32_t m_ = w2; m_; m_ &= m_ - 1)
           __hip_atomic_store(sub2 + ex2++, 32u * threadIdx.x + (uint32_t)(__ffs((int)m_) - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -957,12 +995,20 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
       __hip_atomic_store(a.wg_part + 4 * wg + 2, (unsigned long long)cnt_wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(a.wg_part + 4 * wg + 3, (unsigned long long)cnt2_wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __threadfence();  // this thread's sub-list entries (and the partial) are visible device-wide ...
+    // a bitmap that is REPLACED (a new working set) is cleared by all workgroups together -- with atomics, the path of the ORs
+    // that rebuild it in the tail, and performed before this workgroup's ticket
+    if (MODE != MODE_CHECK && a.merge_into && a.overwrite)
+      for (int64_t w = (int64_t)wg * PAIR_THREADS + threadIdx.x; w < a.words; w += (int64_t)n_wg * PAIR_THREADS) atomicAnd(a.merge_into + w, 0u);
+    if (spec)
+      for (int64_t w = (int64_t)wg * PAIR_THREADS + threadIdx.x; w < a.words; w += (int64_t)n_wg * PAIR_THREADS) atomicAnd(a.spec_bitmap + w, 0u);
+    SMALL_STAMP(3);
+    wait_stores_performed();  // this thread's sub-list entries, bitmap words, positions (all written through) are in place ...
     __syncthreads();
     if (threadIdx.x == 0) last_sh = atomicAdd(a.ticket, 1u) == n_wg - 1 ? 1 : 0;  // ... before the ticket is taken
     __syncthreads();
     if (!last_sh) return;
-    __threadfence();
+    SMALL_STAMP(4);
+    SMALL_STAMP(5);  // (no acquire fence: everything below that other workgroups wrote is read with load_coherent / atomics)
     // ---- (b) tail: the last workgroup alone.  Work ~ workgroups + marked rows, not ~ bitmap words ----
     const int G = (int)((n_wg + PAIR_THREADS - 1) / PAIR_THREADS);  // consecutive workgroups per thread (<= 8)
     double m = VIOL ? -INF : INF;
@@ -985,10 +1031,6 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
     // one list: the sub-lists `which` of all workgroups, concatenated in workgroup (= row) order -> rows_out; their bits are
     // merged into (all or nothing: a list that is too short is repeated) or replace (overwrite) the bitmap bm
     auto emit = [&](int which, int64_t* rows_out, int64_t cap_out, uint32_t* bm, bool overwrite_) -> int {
-      if (bm && overwrite_) {  // a new working set: the bitmap is rebuilt from nothing (atomics only: the path of the ORs below)
-        for (int64_t w = threadIdx.x; w < a.words; w += PAIR_THREADS) atomicAnd(bm + w, 0u);
-        __threadfence();  // (performed before any OR below is issued: barriers follow)
-      }
       int cnt[SCP_SMALL_MAX_WG / PAIR_THREADS], mine = 0;
 #pragma unroll
       for (int e = 0; e < SCP_SMALL_MAX_WG / PAIR_THREADS; ++e) {
@@ -1006,64 +1048,133 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
       }
       if (threadIdx.x == 0) woff[n_wg] = total;
       __syncthreads();
-      const bool overflow = bm != nullptr && !overwrite_ && (int64_t)total > cap_out;
-      for (int sl = threadIdx.x; sl < total; sl += PAIR_THREADS) {
-        int lo = 0, hi = (int)n_wg;  // the workgroup whose sub-list holds slot sl: the last g with woff[g] <= sl
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (woff[mid] <= sl) lo = mid;
-          else hi = mid;
+      const bool overflow = bm != nullptr && !overwrite_ && (int64_t)total > cap_out;  // (a merging pass merges all or nothing)
+      constexpr int EB = 8;  // slots per thread and pass: their sub-list loads (past the L2: ~1 us each) are in flight together
+      for (int s0 = threadIdx.x; s0 < total; s0 += EB * PAIR_THREADS) {
+        int lo_[EB];
+        uint32_t o_[EB];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+          const int sl = s0 + e * PAIR_THREADS;
+          int lo = 0, hi = (int)n_wg;  // the workgroup whose sub-list holds slot sl: the last g with woff[g] <= sl
+          if (sl < total) {
+            while (hi - lo > 1) {
+              const int mid = (lo + hi) >> 1;
+              if (woff[mid] <= sl) lo = mid;
+              else hi = mid;
+            }
+            o_[e] = __hip_atomic_load(a.wg_rows + ((size_t)which * n_wg + lo) * SMALL_ROWS + (sl - woff[lo]), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+          }
+          lo_[e] = lo;
         }
-        const uint32_t o = __hip_atomic_load(a.wg_rows + ((size_t)which * n_wg + lo) * PAIR_ROWS + (sl - woff[lo]), __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT);
-        const int64_t kg = lo / (int)gridDim.x, xg = lo % (int)gridDim.x;
-        const int64_t q_loc = xg * PAIR_ROWS - ((kg * nq) & 1) + (int64_t)o;  // pair offset within [q_begin, q_end)
-        if (!overflow && sl < cap_out) rows_out[sl] = kg * a.pairs + a.q_begin + q_loc;
-        if (bm && !overflow) {
-          const int64_t lr = kg * nq + q_loc;
-          atomicOr(bm + (lr >> 5), 1u << (lr & 31));
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+          const int sl = s0 + e * PAIR_THREADS;
+          if (sl >= total) continue;
+          const int64_t kg = lo_[e] / (int)gridDim.x, xg = lo_[e] % (int)gridDim.x;
+          const int64_t q_loc = xg * SMALL_ROWS - ((kg * nq) & 1) + (int64_t)o_[e];  // pair offset within [q_begin, q_end)
+          if (!overflow && sl < cap_out) rows_out[sl] = kg * a.pairs + a.q_begin + q_loc;
+          if (bm && !overflow) {
+            const int64_t lr = kg * nq + q_loc;
+            atomicOr(bm + (lr >> 5), 1u << (lr & 31));
+          }
         }
       }
       __syncthreads();  // (woff is free again)
       return total;
     };
     int total = 0, total2 = 0;
+    SMALL_STAMP(6);
     if (MODE != MODE_CHECK) total = emit(0, a.rows, a.cap, a.merge_into, a.overwrite != 0);
     else __syncthreads();
+    SMALL_STAMP(7);
     if (spec) total2 = emit(1, a.spec_rows, a.spec_cap, a.spec_bitmap, true);
+    SMALL_STAMP(8);
     if (SPEC && a.mirror && threadIdx.x == 0)
       __hip_atomic_store((unsigned long long*)&a.mirror->n_spec, (unsigned long long)(spec ? total2 : 0), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_SYSTEM);
-    if (MODE == MODE_VIOL_RECOMPUTE && a.rel_prev && a.mirror) {  // rel_step_partial_kernel, block after block
-      __shared__ double rs0[PAIR_THREADS / 64], rs1[PAIR_THREADS / 64];
+    if (MODE == MODE_VIOL_RECOMPUTE && a.rel_prev && a.mirror) {
+      // rel_step_partial_kernel, block after block: thread t of "block" b sums the elements t + 256 (b + j blocks), the wave
+      // butterfly and the (w0 + w1) + (w2 + w3) combination are that kernel's -- the same sums, bit for bit.  No barrier
+      // between the blocks: their loads overlap.
+      __shared__ double rs0[32][PAIR_THREADS / 64], rs1[32][PAIR_THREADS / 64];
       const int64_t n = (int64_t)N * a.K * D, C = (int64_t)N * D;
-      for (int b = 0; b < a.rel_blocks; ++b) {
-        double d2 = 0.0, b2 = 0.0;
-        for (int64_t t = (int64_t)b * 256 + threadIdx.x; t < n; t += (int64_t)a.rel_blocks * 256) {
-          const int d = (int)(t % D), kk = (int)((t / D) % a.K);
-          const int64_t i = t / ((int64_t)D * a.K);
-          rel_accum(a.x_tm[(int64_t)kk * C + i * D + d], a.rel_prev[t], d2, b2);  // (x_out[t] = x_tm[k][c])
+      constexpr int RB = 8;  // blocks whose loads are in flight together
+      for (int b0 = 0; b0 < a.rel_blocks; b0 += RB) {
+        double d2[RB], b2[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) d2[u] = b2[u] = 0.0;
+        // x_out[t] = x_tm[k][c], read from the QP's own (time-major) array: written by an EARLIER kernel, so ordinary cached
+        // loads do.  RB blocks x RQ grid-stride steps = 32 + 32 loads are issued before the first sum needs one (one load per
+        // sum is a chain of ~50 memory latencies per thread: 18 us).
+        constexpr int RQ = 4;
+        const unsigned stride = (unsigned)a.rel_blocks * 256u, un = (unsigned)n;  // (n < 2^31 for a small problem)
+        // (i, k, d) of every block's current element, advanced by the stride without divisions (a 32-bit division is ~40
+        // instructions; two per element were 7 us of this tail)
+        const unsigned s_d = stride % (unsigned)D, s_td = stride / (unsigned)D;
+        const unsigned s_k = s_td % (unsigned)a.K, s_i = s_td / (unsigned)a.K;
+        unsigned ei[RB], ek[RB], ed[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const unsigned t = (unsigned)(b0 + u) * 256u + threadIdx.x;
+          const unsigned td = t / (unsigned)D;
+          ed[u] = t - td * (unsigned)D;
+          ei[u] = td / (unsigned)a.K;
+          ek[u] = td - ei[u] * (unsigned)a.K;
+        }
+        for (unsigned j0 = 0; (unsigned)b0 * 256u + j0 * stride < un; j0 += RQ) {
+          double xv[RB][RQ], yv[RB][RQ];
+#pragma unroll
+          for (int u = 0; u < RB; ++u) {
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+              const unsigned t = (unsigned)(b0 + u) * 256u + threadIdx.x + (j0 + q) * stride;
+              const bool ok = b0 + u < a.rel_blocks && t < un;
+              xv[u][q] = a.x_tm[ok ? (int64_t)ek[u] * C + (int64_t)ei[u] * D + ed[u] : 0];
+              yv[u][q] = a.rel_prev[ok ? t : 0u];
+              ed[u] += s_d;
+              if (ed[u] >= (unsigned)D) { ed[u] -= (unsigned)D; ++ek[u]; }
+              ek[u] += s_k;
+              if (ek[u] >= (unsigned)a.K) { ek[u] -= (unsigned)a.K; ++ei[u]; }
+              if (ek[u] >= (unsigned)a.K) { ek[u] -= (unsigned)a.K; ++ei[u]; }  // (the carry from d on top of s_k)
+              ei[u] += s_i;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < RB; ++u) {
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) {
+              const unsigned t = (unsigned)(b0 + u) * 256u + threadIdx.x + (j0 + q) * stride;
+              if (b0 + u < a.rel_blocks && t < un) rel_accum(xv[u][q], yv[u][q], d2[u], b2[u]);
+            }
+          }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          d2 += __shfl_xor(d2, o);
-          b2 += __shfl_xor(b2, o);
-        }
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) {
-          rs0[threadIdx.x >> 6] = d2;
-          rs1[threadIdx.x >> 6] = b2;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-          __hip_atomic_store((unsigned long long*)&a.mirror->rel[2 * b],
-                             (unsigned long long)__double_as_longlong((rs0[0] + rs0[1]) + (rs0[2] + rs0[3])), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_SYSTEM);
-          __hip_atomic_store((unsigned long long*)&a.mirror->rel[2 * b + 1],
-                             (unsigned long long)__double_as_longlong((rs1[0] + rs1[1]) + (rs1[2] + rs1[3])), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int u = 0; u < RB; ++u) {
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            d2[u] += __shfl_xor(d2[u], o);
+            b2[u] += __shfl_xor(b2[u], o);
+          }
+          if (b0 + u < a.rel_blocks && (threadIdx.x & 63) == 0) {
+            rs0[b0 + u][threadIdx.x >> 6] = d2[u];
+            rs1[b0 + u][threadIdx.x >> 6] = b2[u];
+          }
         }
       }
+      __syncthreads();
+      if ((int)threadIdx.x < a.rel_blocks) {
+        const int b = threadIdx.x;
+        __hip_atomic_store((unsigned long long*)&a.mirror->rel[2 * b],
+                           (unsigned long long)__double_as_longlong((rs0[b][0] + rs0[b][1]) + (rs0[b][2] + rs0[b][3])),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((unsigned long long*)&a.mirror->rel[2 * b + 1],
+                           (unsigned long long)__double_as_longlong((rs1[b][0] + rs1[b][1]) + (rs1[b][2] + rs1[b][3])),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        wait_stores_performed();  // (written through to host memory before thread 0 stores the sequence number: a barrier follows)
+      }
+      __syncthreads();
     }
     if (threadIdx.x == 0) {
       m = red_d[0];
@@ -1073,6 +1184,9 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
         m = VIOL ? fmax(m, red_d[w]) : fmin(m, red_d[w]);
         f = red_u[w] < f ? red_u[w] : f;
       }
+#ifdef SCP_PHASE_PROFILE
+      small_clk_local[9] = __builtin_amdgcn_s_memrealtime();
+#endif
       scp_pair_stats st;
       st.min_dist = VIOL ? INF : m;
       st.first_violation = f;
@@ -1104,7 +1218,14 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
                            __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store((unsigned long long*)&a.mirror->stats.max_violation,
                            (unsigned long long)__double_as_longlong(st.max_violation), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store((unsigned long long*)&a.mirror->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // every field above was written through to host memory: waiting for the acknowledgements orders the sequence number
+        // behind them without a system-scope release fence (an L2 write-back: ~10 us in this tail)
+        wait_stores_performed();
+        __hip_atomic_store((unsigned long long*)&a.mirror->seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef SCP_PHASE_PROFILE
+        small_clk_local[10] = __builtin_amdgcn_s_memrealtime();
+        for (int i_ = 0; i_ < 11; ++i_) scp_small_clk[i_] = small_clk_local[i_];
+#endif
       }
     }
     return;
@@ -1194,7 +1315,7 @@ struct PassTail {
 static bool small_pass_ok(const scp_ctx* ctx, int N, int K, int D, int64_t nq, int n_slices) {
   if (!ctx->small_pass || nq <= 0) return false;
   const int64_t words = (K * nq + 31) / 32;
-  const int64_t n_wg = (int64_t)scp_cdiv(nq + 1, PAIR_ROWS) * K;
+  const int64_t n_wg = (int64_t)scp_cdiv(nq + 1, SMALL_ROWS) * K;
   return words <= CMP1_MAX_WORDS && (size_t)n_slices * N * D * sizeof(double) <= 32 * 1024 && n_wg <= SCP_SMALL_MAX_WG;
 }
 
@@ -1214,7 +1335,7 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
       a.pos_a = pos_ref_layout;
       if (MODE == MODE_VIOL_RECOMPUTE && !a.x_tm) a.pos_b = p0;
       if (MODE != MODE_CHECK) {  // per-workgroup sub-lists of the marked rows (grown on demand, owned by the ctx)
-        const size_t need = (size_t)(a.spec_rows ? 2 : 1) * scp_cdiv(nq + 1, PAIR_ROWS) * K * PAIR_ROWS * sizeof(uint32_t);
+        const size_t need = (size_t)(a.spec_rows ? 2 : 1) * scp_cdiv(nq + 1, SMALL_ROWS) * K * SMALL_ROWS * sizeof(uint32_t);
         if (ctx->wg_rows_bytes < need) {
           if (ctx->wg_rows) {
             SCP_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1233,8 +1354,12 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
       a.words = tail->words;
       a.mirror = ctx->d_mirror;
       a.seq = ++ctx->mirror_seq;
+#ifdef SCP_PHASE_PROFILE
+      a.ablate = getenv("SCP_PAIR_ABLATE") ? atoi(getenv("SCP_PAIR_ABLATE")) : 0;
+#else
       a.ablate = 0;
-      dim3 grid(scp_cdiv(nq + 1, PAIR_ROWS), K);
+#endif
+      dim3 grid(scp_cdiv(nq + 1, SMALL_ROWS), K);
       if (ctx->timing) SCP_HIP_CHECK(ctx, hipEventRecord(ctx->pair_ev0, ctx->stream));
       if (D == 2) hipLaunchKernelGGL((pair_pass_kernel<2, MODE, true, true>), grid, dim3(PAIR_THREADS), lds_small, ctx->stream, a);
       else hipLaunchKernelGGL((pair_pass_kernel<3, MODE, true, true>), grid, dim3(PAIR_THREADS), lds_small, ctx->stream, a);
@@ -1295,6 +1420,10 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
 
 #ifdef SCP_PHASE_PROFILE
 // developer hook of the profiling build only (not declared in include/scp_hip.h): the per-workgroup stamps above
+extern "C" int scp_debug_small_clocks(unsigned long long* out, int n) {
+  if (n > 16) n = 16;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(scp_small_clk), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
 extern "C" int scp_debug_pair_clocks(unsigned long long* out, int n) {
   if (n > 2 * SCP_PAIR_CLK_WGS) n = 2 * SCP_PAIR_CLK_WGS;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(scp_pair_clk), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;

@@ -65,12 +65,22 @@ timeout -k 10 400 python3 tools/soak.py 24 --large > $OUT/soak_24_large.txt 2>&1
 # cold figure (solver creation and kernel loading inside the clock) for one process
 TRIALS=256 bash tools/batch_rate.sh $OUT/batch128_rates.txt "1:1 1:4 2:4 4:4 4:5" > /dev/null 2>&1
 TRIALS=96 WARMUP=0 bash tools/batch_rate.sh $OUT/batch128_cold.txt "1:1 1:4" > /dev/null 2>&1
+# the same layouts with the kernel-timing events on and with the multi-launch form of the pairwise passes (what the one-launch
+# passes and the missing events are worth), and what the records of the 4 x 5 run say (pipelines, give-ups, stragglers)
+python3 tools/batch_records_summary.py /tmp/b_4_5 4 > $OUT/batch128_records_4x5.txt 2>&1
+TRIALS=256 EXTRA="--kernel-timing 1" bash tools/batch_rate.sh $OUT/batch128_with_events.txt "1:4 4:5" > /dev/null 2>&1
+SCP_NO_SMALL_PASS=1 TRIALS=256 bash tools/batch_rate.sh $OUT/batch128_multi_launch_passes.txt "1:1 1:4 4:5" > /dev/null 2>&1
 cat $OUT/batch128_rates.txt $OUT/batch128_cold.txt
 cd /tmp
 timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_solve128 -- python3 $R/tools/solve128.py 128 8 > $OUT/solve128.log 2>&1
 cp $(find $OUT/prof_solve128 -name "*kernel_stats.csv" | head -1) $OUT/solve128_kernel_stats.csv 2>/dev/null
 grep "^solve" $OUT/solve128.log > $OUT/solve128.txt
+cp $(find $OUT/prof_solve128 -name "*kernel_trace.csv" | head -1) $OUT/solve128_kernel_trace.csv 2>/dev/null
 cd $R
+python3 tools/solve_timeline.py $OUT/solve128_kernel_trace.csv > $OUT/solve128_timeline.txt 2>&1
+SCP_HIP_LIB=$R/ba-path-planning_amd/lib/libscp_hip_prof.so timeout -k 10 100 python3 tools/small_pass_profile.py 128 > $OUT/small_pass_profile_n128.txt 2>&1
+SCP_HIP_LIB=$R/ba-path-planning_amd/lib/libscp_hip_prof.so timeout -k 10 100 python3 tools/small_pass_profile.py 256 > $OUT/small_pass_profile_n256.txt 2>&1
+cat $OUT/small_pass_profile_n128.txt
 timeout -k 10 100 python3 tools/demo_k500.py > $OUT/demo_k500.txt 2>&1; tail -5 $OUT/demo_k500.txt
 timeout -k 10 60 tools/bin/grid_sync_bench 2000 > $OUT/grid_sync_bench.txt 2>&1
 echo "== done"

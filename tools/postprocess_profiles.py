@@ -28,6 +28,9 @@ COPIES = {
     "batch128_rates.txt": "batch128_rates.txt", "batch128_cold.txt": "batch128_cold.txt", "demo_k500.txt": "demo_k500.txt",
     "grid_sync_bench.txt": "grid_sync_bench.txt", "solve128.txt": "solve128.txt",
     "solve128_kernel_stats.csv": "solve128_kernel_stats.csv",
+    "batch128_with_events.txt": "batch128_with_events.txt", "batch128_multi_launch_passes.txt": "batch128_multi_launch_passes.txt",
+    "batch128_records_4x5.txt": "batch128_records_4x5.txt", "solve128_timeline.txt": "solve128_timeline.txt",
+    "small_pass_profile_n128.txt": "small_pass_profile_n128.txt", "small_pass_profile_n256.txt": "small_pass_profile_n256.txt",
     "bench_n4096_1gpu_kernel_stats.csv": "bench_n4096_1gpu_kernel_stats.csv",
     "phase_profile_lean_n4096.txt": "phase_profile_lean_n4096.txt", "step_time.txt": "step_time.txt",
     "phase_profile_round2_kernel_n1024.txt": "phase_profile_round2_kernel_n1024.txt",

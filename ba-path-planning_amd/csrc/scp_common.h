@@ -112,6 +112,9 @@ int scp_launch_kinematics_copy(scp_ctx* ctx, int N, int K, int D, double h, cons
 // the QP's current iterate in its own layout ([K][N D], device pointer)
 const double* scp_qp_solution_tm(const scp_qp* qp);
 
+// scp_qp_reset(x0) + scp_qp_add_rows_at(rows): one launch when the problem is small, the two calls otherwise (same bits)
+int scp_qp_reset_add_rows_at(scp_qp* qp, const double* x0, int64_t n, const int64_t* rows, const double* pos_prev,
+                             const double* p0, const double* v0, double R);
 // scp_gather_rows + scp_qp_add_rows in one launch: eta / l_col are the outputs of scp_linearize_pairs over [q_begin, q_end)
 int scp_qp_add_rows_from_pass(scp_qp* qp, int64_t n, const int64_t* rows, const double* eta, const double* l_col,
                               int64_t q_begin, int64_t q_end);

@@ -623,17 +623,6 @@ __device__ unsigned long long scp_small_clk[16];
 
 __device__ inline int block_exclusive_scan(int v, int* total);  // (256 threads; defined with the compaction kernels below)
 
-// Data one workgroup of a small-problem pass hands to the LAST workgroup of the same kernel (possibly on another XCD, behind
-// another L2): written through to the device's coherence point and read past the local L2.  With every such store written
-// through, "my stores have been performed" is a wait for their acknowledgements -- no L2 write-back (a __threadfence() per
-// workgroup walks the L2 each time: 9 us at 200 workgroups).
-__device__ inline void store_coherent(double* p, double v) {
-  __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ inline double load_coherent(const double* p) {
-  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ inline void wait_stores_performed() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
 // SMALL (problems whose bitmap one workgroup compacts: <= 2 M rows, e.g. 128 agents x 50 steps): the pass is ONE launch.
 // Every workgroup stages its time step straight from the [N][K][D] arrays (no prep kernel) -- the violations pass can even
@@ -827,13 +816,26 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
     }
 
     bool any_sel = false;
+    // STREAM (interior workgroups of the linearisation): the rare events of a row -- a degenerate pair (scp.py:503), a
+    // distance below R - 0.01 (scp.py:610) -- are only FLAGGED in the row loop and handled behind one branch per group
+    // afterwards; the loop itself runs pair_row_regular (no selects).  Same values: the repair calls pair_row.
+    constexpr bool STREAM = MODE == MODE_LINEARIZE && FULL;
+    double raw_v[PAIR_UNROLL][2];
+    double raw_min = INF;  // over the group's rows: ONE comparison per group and event decides whether any row needs a closer look
 #pragma unroll
     for (int u = 0; u < PAIR_UNROLL; ++u) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int i = pi_[u][e], j = pj_[u][e];
         sel[u][e] = false;
-        if (MODE != MODE_VIOLATIONS) {
+        if (STREAM) {
+          const Pt<D> Pi = load_pt<D>(P, i), Pj = load_pt<D>(P, j);
+          const PairGeom<D> g = pair_geom<D>(Pi, Pj);
+          raw_v[u][e] = g.raw;
+          raw_min = fmin(raw_min, g.raw);
+          const Pt<D> Qi = load_pt<D>(Q, i), Qj = load_pt<D>(Q, j);
+          pair_row_regular<D>(g, Qi, Qj, a.R, eta_v[u][e], l_v[u][e]);
+        } else if (MODE != MODE_VIOLATIONS) {
           const Pt<D> Pi = load_pt<D>(P, i), Pj = load_pt<D>(P, j);
           const PairGeom<D> g = pair_geom<D>(Pi, Pj);
           const double* diff = g.diff;
@@ -890,6 +892,46 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
         any_sel |= sel[u][e];
       }
     }
+    if (STREAM) {
+      my_min = fmin(my_min, raw_min);
+      // (x -> x - R is monotone, so "some row passes the selection test" implies "the smallest distance passes it")
+      if ((raw_min - a.R) < a.margin) {
+#pragma unroll
+        for (int u = 0; u < PAIR_UNROLL; ++u)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            sel[u][e] = (raw_v[u][e] - a.R) < a.margin;
+            any_sel |= sel[u][e];
+          }
+      }
+      if (raw_min < thr) {
+#pragma unroll
+        for (int u = 0; u < PAIR_UNROLL; ++u)
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            if (raw_v[u][e] < thr) {
+              const int64_t off = off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS) + e;
+              const unsigned long long g_ = (unsigned long long)((int64_t)k * a.pairs + a.q_begin + off);
+              my_first = g_ < my_first ? g_ : my_first;
+            }
+      }
+      if (raw_min < 2e-6) {  // (a degenerate pair has dist^2 < 1e-12: the exact test is g.deg below)
+        any_sel = false;
+#pragma unroll
+        for (int u = 0; u < PAIR_UNROLL; ++u)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int i = pi_[u][e], j = pj_[u][e];
+            const PairGeom<D> g = pair_geom<D>(load_pt<D>(P, i), load_pt<D>(P, j));
+            if (g.deg) {
+              double dist;
+              pair_row<D>(g, load_pt<D>(Q, i), load_pt<D>(Q, j), a.R, eta_v[u][e], l_v[u][e], dist);
+              sel[u][e] = (dist - a.R) < a.margin;
+            }
+            any_sel |= sel[u][e];
+          }
+      }
+    }
 
     if (MODE == MODE_LINEARIZE && (a.ablate & 1)) {
 #pragma unroll
@@ -902,7 +944,16 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
       for (int u = 0; u < PAIR_UNROLL; ++u) {
         const int64_t lrA = slice0 + off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS);  // even by construction
         const int o32 = o0 + (s0 + u) * (2 * PAIR_THREADS);
-        if (FULL || (valid[u][0] && valid[u][1])) {
+        if (FULL) {
+          // wave-uniform plane bases + an UNSIGNED 32-bit byte offset per lane (host: 8 nq < 2^32): the saddr form of the
+          // store, one vector add per step instead of a 64-bit address per plane
+          const uint32_t bo = (uint32_t)o32 * 8u;
+#pragma unroll
+          for (int d = 0; d < D; ++d)
+            *reinterpret_cast<double2*>(reinterpret_cast<char*>(eta_k + d * a.eta_stride) + bo) =
+                make_double2(eta_v[u][0][d], eta_v[u][1][d]);
+          *reinterpret_cast<double2*>(reinterpret_cast<char*>(l_k) + bo) = make_double2(l_v[u][0], l_v[u][1]);
+        } else if (valid[u][0] && valid[u][1]) {
 #pragma unroll
           for (int d = 0; d < D; ++d)
             *reinterpret_cast<double2*>(eta_k + d * a.eta_stride + o32) = make_double2(eta_v[u][0][d], eta_v[u][1][d]);

@@ -6,6 +6,19 @@
 
 #include <cstdint>
 
+// Data one workgroup of a kernel hands to its LAST workgroup (the one-launch pairwise passes of small problems, the kernel that
+// resets a QP and installs its rows) (possibly on another XCD, behind
+// another L2): written through to the device's coherence point and read past the local L2.  With every such store written
+// through, "my stores have been performed" is a wait for their acknowledgements -- no L2 write-back (a __threadfence() per
+// workgroup walks the L2 each time: 9 us at 200 workgroups).
+__device__ inline void store_coherent(double* p, double v) {
+  __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline double load_coherent(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ inline void wait_stores_performed() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+
 // Lexicographic pair index q -> (i, j), i < j.  Row i of the triangle starts at off(i) = i (2N - i - 1) / 2.
 __device__ __host__ inline int64_t tri_off(int64_t i, int64_t N) { return i * (2 * N - i - 1) / 2; }
 
@@ -93,12 +106,28 @@ __device__ inline void pair_row(const PairGeom<D>& g, const Pt<D>& Qi, const Pt<
   l = (R - dist) + qd;
 }
 
+// pair_row for a pair that is NOT degenerate (g.deg false): the same operations on the same operands without the selects
+// -- the streaming kernel runs this on every row and repairs the (rare) degenerate ones with pair_row afterwards.
+template <int D>
+__device__ inline void pair_row_regular(const PairGeom<D>& g, const Pt<D>& Qi, const Pt<D>& Qj, double R, double (&eta)[D],
+                                        double& l) {
+  double qd = 0.0;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const double e_d = g.diff[d] * g.inv;
+    eta[d] = e_d;
+    qd = fma(e_d, Qi.v[d] - Qj.v[d], qd);
+  }
+  l = (R - g.raw) + qd;
+}
+
 
 // Working row `base + t` of a QP with eta / l RECOMPUTED from the linearisation point (scp_qp_add_rows_at; the row-free loop:
 // scp_select_pairs wrote no rows): decode (k, i, j), the two positions of the pair at step k from pos_prev ([N][K][D]), then
 // pair_geom / pair_row -- the very functions of the linearisation kernel, on the same operands (Q = P - free_motion as its
 // prep kernel forms it): bit-identical eta and l.  z = max(A x, l), y = 0 as add_rows_kernel.
-template <int D>
+// COH: Qx was written by other workgroups of the SAME kernel (reset + install in one launch): read past the local L2.
+template <int D, bool COH = false>
 __device__ inline void add_row_at(int64_t t, int N, int K, int64_t C, int64_t pairs, int64_t base,
                                   const int64_t* __restrict__ rows, const double* __restrict__ pos_prev,
                                   const double* __restrict__ p0, const double* __restrict__ v0, double R, double h,
@@ -129,7 +158,9 @@ __device__ inline void add_row_at(int64_t t, int N, int K, int64_t C, int64_t pa
 #pragma unroll
   for (int d = 0; d < D; ++d) {
     weta[o * D + d] = eta[d];
-    ax += eta[d] * (Qx[(int64_t)k * C + (int64_t)i * D + d] - Qx[(int64_t)k * C + (int64_t)j * D + d]);
+    const double qi = COH ? load_coherent(Qx + (int64_t)k * C + (int64_t)i * D + d) : Qx[(int64_t)k * C + (int64_t)i * D + d];
+    const double qj = COH ? load_coherent(Qx + (int64_t)k * C + (int64_t)j * D + d) : Qx[(int64_t)k * C + (int64_t)j * D + d];
+    ax += eta[d] * (qi - qj);
   }
   wl[o] = l;
   zc[o] = fmax(ax, l);

@@ -18,6 +18,7 @@
 // stacked as  [0,K-1) jerk | [K-1,2K-1) acc | [2K-1,3K-1) vel | [3K-1,4K-1) pos.
 // oracle/qp_oracle.py:admm_structured is the line-by-line CPU statement of this file.
 #include "scp_qp_internal.h"
+#include "scp_reset_device.h"
 
 #include <chrono>
 #include <cmath>
@@ -407,58 +408,13 @@ __global__ __launch_bounds__(256) void add_rows_kernel(int N, int D, int64_t C, 
 // scp_qp_reset in one launch (K <= SCP_FUSED_MAX_K): x0 in reference order [N][K][D] (null: zeros) -> x (time-major),
 // z_f = F x, the carried F x and S0 x of the single-step pipeline (exact), y_f = 0.  16 columns per workgroup (256 columns
 // of a 128-agent problem still make 16 workgroups), the x tile in LDS, thread = (column, one sixteenth of the rows).
-constexpr int RESET_COLS = 16;
 __global__ __launch_bounds__(256) void qp_reset_kernel(int N, int K, int D, int Rf, const double* __restrict__ x0,
                                                         const double* __restrict__ F, const double* __restrict__ S0,
                                                         double* __restrict__ x, double* __restrict__ zf,
                                                         double* __restrict__ fx, double* __restrict__ Qx,
                                                         double* __restrict__ yf) {
   extern __shared__ double reset_xs[];  // [K][RESET_COLS]
-  constexpr int RG = 256 / RESET_COLS;
-  const int64_t C = (int64_t)N * D;
-  const int lc = threadIdx.x & (RESET_COLS - 1), rg = threadIdx.x / RESET_COLS;
-  const int64_t c = (int64_t)blockIdx.x * RESET_COLS + lc;
-  const bool live = c < C;
-  const int64_t agent = live ? c / D : 0;
-  const int dim = live ? (int)(c - agent * D) : 0;
-  for (int k = rg; k < K; k += RG) {
-    const double v = (live && x0) ? x0[(agent * K + k) * D + dim] : 0.0;
-    reset_xs[k * RESET_COLS + lc] = v;
-    if (live) x[(int64_t)k * C + c] = v;
-  }
-  __syncthreads();
-  // four rows per thread and pass: one LDS read of x[k] feeds four independent multiply-add chains (one row at a time was
-  // a chain of K dependent loads + FMAs per row: 42 us at 1024 agents)
-  constexpr int RB = 4;
-  for (int r0 = rg * RB; r0 < Rf + K; r0 += RG * RB) {
-    const double* __restrict__ row[RB];
-    double acc[RB];
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      const int r = min(r0 + j, Rf + K - 1);
-      row[j] = r < Rf ? F + (size_t)r * K : S0 + (size_t)(r - Rf) * K;
-      acc[j] = 0.0;
-    }
-#pragma unroll 2
-    for (int k = 0; k < K; ++k) {
-      const double xv = reset_xs[k * RESET_COLS + lc];
-#pragma unroll
-      for (int j = 0; j < RB; ++j) acc[j] += row[j][k] * xv;
-    }
-    if (!live) continue;
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      const int r = r0 + j;
-      if (r >= Rf + K) break;
-      if (r < Rf) {
-        zf[(int64_t)r * C + c] = acc[j];
-        fx[(int64_t)r * C + c] = acc[j];
-        yf[(int64_t)r * C + c] = 0.0;
-      } else {
-        Qx[(int64_t)(r - Rf) * C + c] = acc[j];
-      }
-    }
-  }
+  qp_reset_body<false>(threadIdx.x, true, reset_xs, N, K, D, Rf, x0, F, S0, x, zf, fx, Qx, yf);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -957,14 +913,30 @@ extern "C" int scp_qp_set_problem(scp_qp* qp, const double* limits, const double
   return SCP_OK;
 }
 
-extern "C" int scp_qp_reset(scp_qp* qp, const double* x0) {
-  if (!qp) return SCP_ERR_INVALID;
+// eta_stride == 0: gathered rows (the public entry point); > 0: eta / l are the arrays of the pairwise pass over the pair
+// range [q_begin, q_begin + nq), gathered by the kernel; at != nullptr: no stored rows at all, eta / l are recomputed from
+// the linearisation point
+struct RowsAt {
+  const double *pos_prev, *p0, *v0;
+  double R;
+};
+
+// scp_qp_reset; with `at`: the QP's first rows (recomputed from the linearisation point, scp_qp_add_rows_at) are installed
+// by the SAME launch when the problem is small (*installed; otherwise only the reset has happened)
+static int reset_impl(scp_qp* qp, const double* x0, int64_t n, const int64_t* rows, const RowsAt* at, bool* installed) {
   scp_ctx* ctx = qp->ctx;
+  if (installed) *installed = false;
   if (!qp->problem_set) return scp_fail(ctx, SCP_ERR_STATE, "qp_reset: call scp_qp_set_problem first");
   const QpDev& d = qp->d;
   const int64_t nx = (int64_t)qp->K * qp->C, nf = (int64_t)qp->Rf * qp->C;
   const bool one_launch = qp->st.use_mfma == 1 && qp->K <= SCP_FUSED_MAX_K;
-  if (one_launch) {
+  qp->rho = qp->st.rho;
+  bool with_rows = false;
+  if (one_launch && at && ctx->small_pass && qp->st.cg_iters == 1 && n > 0 && n <= qp->row_cap)
+    QP_CHECK(scp_qp_reset_install_small(qp, x0, n, rows, at->pos_prev, at->p0, at->v0, at->R, d.HQ + nx, &with_rows));
+  if (with_rows) {
+    qp->qx_sel = 0;
+  } else if (one_launch) {
     // z = A x (primal warm start, scp.py:443), y = 0 and the single-step pipeline's carried F x, S0 x in one launch
     hipLaunchKernelGGL(qp_reset_kernel, dim3(scp_cdiv(qp->C, RESET_COLS)), dim3(256),
                        (size_t)qp->K * RESET_COLS * sizeof(double), ctx->stream, qp->N, qp->K, qp->D, qp->Rf, x0, d.F, d.S0,
@@ -977,18 +949,23 @@ extern "C" int scp_qp_reset(scp_qp* qp, const double* x0) {
     QP_CHECK(gemm(qp, qp->Rf, qp->K, 1.0, d.F, d.x, 0.0, d.zf));  // z = A x  (primal warm start, scp.py:443)
     SCP_HIP_CHECK(ctx, hipMemsetAsync(d.yf, 0, nf * sizeof(double), ctx->stream));
   }
-  qp->nW = 0;
+  qp->nW = with_rows ? n : 0;
   qp->persist_cap_nW = -1;
   qp->persist_off = false;  // every new QP tries the persistent path again
   qp->steps_since_reset = 0;
-  qp->rho = qp->st.rho;
   qp->cg1_ready = false;
-  qp->gval_valid = false;
-  qp->csr_valid = false;
+  qp->gval_valid = with_rows;  // (incidence lists and row values of the installed rows, at gval_rho_c)
+  qp->csr_valid = with_rows;
   qp->qx_fresh = one_launch;  // F x and S0 x of this x are in place
   QP_CHECK(build_kkt(qp));
   qp->reset_done = true;
+  if (installed) *installed = with_rows;
   return SCP_OK;
+}
+
+extern "C" int scp_qp_reset(scp_qp* qp, const double* x0) {
+  if (!qp) return SCP_ERR_INVALID;
+  return reset_impl(qp, x0, 0, nullptr, nullptr, nullptr);
 }
 
 extern "C" int scp_qp_set_rho(scp_qp* qp, double rho) {
@@ -1001,13 +978,6 @@ extern "C" int scp_qp_set_rho(scp_qp* qp, double rho) {
   return build_kkt(qp);
 }
 
-// eta_stride == 0: gathered rows (the public entry point); > 0: eta / l are the arrays of the pairwise pass over the pair
-// range [q_begin, q_begin + nq), gathered by the kernel; at != nullptr: no stored rows at all, eta / l are recomputed from
-// the linearisation point
-struct RowsAt {
-  const double *pos_prev, *p0, *v0;
-  double R;
-};
 static int add_rows_impl(scp_qp* qp, int64_t n, const int64_t* rows, const double* eta, const double* l, int64_t eta_stride,
                          int64_t q_begin, int64_t nq, const RowsAt* at = nullptr) {
   scp_ctx* ctx = qp->ctx;
@@ -1062,6 +1032,19 @@ extern "C" int scp_qp_add_rows_at(scp_qp* qp, int64_t n, const int64_t* rows, co
   if (!qp) return SCP_ERR_INVALID;
   SCP_REQUIRE(qp->ctx, n <= 0 || (pos_prev && p0 && v0), "qp_add_rows_at: null pointer");
   const RowsAt at{pos_prev, p0, v0, R};
+  return add_rows_impl(qp, n, rows, nullptr, nullptr, 0, 0, 1, &at);
+}
+
+// scp_qp_reset(x0) followed by scp_qp_add_rows_at(rows): one launch for small problems (used by the native SCP loop), the
+// two calls otherwise.  Same state, same bits either way.
+int scp_qp_reset_add_rows_at(scp_qp* qp, const double* x0, int64_t n, const int64_t* rows, const double* pos_prev,
+                             const double* p0, const double* v0, double R) {
+  if (!qp) return SCP_ERR_INVALID;
+  SCP_REQUIRE(qp->ctx, n <= 0 || (rows && pos_prev && p0 && v0), "qp_reset_add_rows_at: null pointer");
+  const RowsAt at{pos_prev, p0, v0, R};
+  bool installed = false;
+  QP_CHECK(reset_impl(qp, x0, n, rows, &at, &installed));
+  if (installed) return SCP_OK;
   return add_rows_impl(qp, n, rows, nullptr, nullptr, 0, 0, 1, &at);
 }
 

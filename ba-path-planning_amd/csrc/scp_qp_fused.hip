@@ -11,6 +11,7 @@
 // for K > 128 and as the use_mfma = 0/2 reference); the arithmetic is the same, statement by statement.
 #include "scp_qp_device.h"
 #include "scp_pair_device.h"
+#include "scp_reset_device.h"
 #include <cstdlib>
 
 namespace {
@@ -1471,7 +1472,8 @@ __global__ __launch_bounds__(256) void csr_finish_kernel(int64_t nent, int D, co
 // Small problems (N K <= CSR1_MAX_CELLS cells, e.g. 128 agents x 50 steps): the whole build -- count, scan, fill, sort,
 // finish -- and the first row values (rows_value_kernel<D, true>) in ONE workgroup; the cell counters live in LDS.  Same lists,
 // same order as the five-launch build.
-__global__ __launch_bounds__(1024) void csr_small_kernel(int64_t nW, int K, int ncell, int D, int64_t C, double rho,
+template <bool COH>
+__device__ inline void csr_small_body(int* csr_cnt, int64_t nW, int K, int ncell, int D, int64_t C, double rho,
                                                           int* __restrict__ wk, int* __restrict__ wi,
                                                           int* __restrict__ wj, double* __restrict__ weta,
                                                           const double* __restrict__ Qx, double* __restrict__ zc,
@@ -1479,7 +1481,7 @@ __global__ __launch_bounds__(1024) void csr_small_kernel(int64_t nW, int K, int 
                                                           int* __restrict__ ent, double* __restrict__ coef,
                                                           int* __restrict__ pos_i, int* __restrict__ pos_j,
                                                           double* __restrict__ gval, CsrNewRows nr) {
-  extern __shared__ int csr_cnt[];  // [ncell]: counts, then exclusive offsets, then fill cursors (= end of each cell)
+  // csr_cnt: [ncell] ints of LDS: counts, then exclusive offsets, then fill cursors (= end of each cell)
   __shared__ int wsum[16];
   constexpr int SC = CSR1_MAX_CELLS / 1024;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1487,10 +1489,10 @@ __global__ __launch_bounds__(1024) void csr_small_kernel(int64_t nW, int K, int 
     const int64_t pairs = (int64_t)nr.N * (nr.N - 1) / 2;
     for (int64_t t = tid; t < nr.n; t += 1024) {
       if (D == 2)
-        add_row_at<2>(t, nr.N, K, C, pairs, nr.base, nr.rows, nr.pos_prev, nr.p0, nr.v0, nr.R, nr.h, Qx, nr.w_row, wk, wi, wj,
+        add_row_at<2, COH>(t, nr.N, K, C, pairs, nr.base, nr.rows, nr.pos_prev, nr.p0, nr.v0, nr.R, nr.h, Qx, nr.w_row, wk, wi, wj,
                       weta, nr.wl, zc, yc);
       else
-        add_row_at<3>(t, nr.N, K, C, pairs, nr.base, nr.rows, nr.pos_prev, nr.p0, nr.v0, nr.R, nr.h, Qx, nr.w_row, wk, wi, wj,
+        add_row_at<3, COH>(t, nr.N, K, C, pairs, nr.base, nr.rows, nr.pos_prev, nr.p0, nr.v0, nr.R, nr.h, Qx, nr.w_row, wk, wi, wj,
                       weta, nr.wl, zc, yc);
     }
     __threadfence_block();
@@ -1561,13 +1563,82 @@ __global__ __launch_bounds__(1024) void csr_small_kernel(int64_t nW, int K, int 
     const int64_t bi = (int64_t)wk[n] * C + (int64_t)wi[n] * D;
     const int64_t bj = (int64_t)wk[n] * C + (int64_t)wj[n] * D;
     double ax = 0.0;
-    for (int d = 0; d < D; ++d) ax += weta[n * D + d] * (Qx[bi + d] - Qx[bj + d]);
+    for (int d = 0; d < D; ++d)
+      ax += weta[n * D + d] * (COH ? load_coherent(Qx + bi + d) - load_coherent(Qx + bj + d) : Qx[bi + d] - Qx[bj + d]);
     const double g = (rho * zc[n] - yc[n]) - rho * ax;
     gval[pos_i[n]] = g;
     gval[pos_j[n]] = g;
   }
 }
 
+__global__ __launch_bounds__(1024) void csr_small_kernel(int64_t nW, int K, int ncell, int D, int64_t C, double rho,
+                                                          int* __restrict__ wk, int* __restrict__ wi,
+                                                          int* __restrict__ wj, double* __restrict__ weta,
+                                                          const double* __restrict__ Qx, double* __restrict__ zc,
+                                                          double* __restrict__ yc, int* __restrict__ ptr,
+                                                          int* __restrict__ ent, double* __restrict__ coef,
+                                                          int* __restrict__ pos_i, int* __restrict__ pos_j,
+                                                          double* __restrict__ gval, CsrNewRows nr) {
+  extern __shared__ int csr_cnt[];
+  csr_small_body<false>(csr_cnt, nW, K, ncell, D, C, rho, wk, wi, wj, weta, Qx, zc, yc, ptr, ent, coef, pos_i, pos_j, gval, nr);
+}
+
+// scp_qp_reset AND the installation of the QP's first rows in ONE launch: every workgroup resets its 16 columns
+// (qp_reset_body: its first 256 threads), S0 x written through; the LAST workgroup to finish (a ticket) then runs
+// csr_small_body on all 1024 threads, reading S0 x past its L2.  Same values as the two launches.
+struct ResetArgs {
+  int N, Rf;
+  const double *x0, *F, *S0;
+  double *x, *zf, *fx, *yf;
+};
+__global__ __launch_bounds__(1024) void reset_install_kernel(ResetArgs ra, int64_t nW, int K, int ncell, int D, int64_t C,
+                                                              double rho, int* __restrict__ wk, int* __restrict__ wi,
+                                                              int* __restrict__ wj, double* __restrict__ weta,
+                                                              double* __restrict__ Qx, double* __restrict__ zc,
+                                                              double* __restrict__ yc, int* __restrict__ ptr,
+                                                              int* __restrict__ ent, double* __restrict__ coef,
+                                                              int* __restrict__ pos_i, int* __restrict__ pos_j,
+                                                              double* __restrict__ gval, CsrNewRows nr,
+                                                              unsigned* __restrict__ ticket) {
+  extern __shared__ __attribute__((aligned(16))) char ri_lds[];  // max([K][16] doubles, [ncell] ints)
+  __shared__ int last_sh;
+  qp_reset_body<true>(threadIdx.x, threadIdx.x < 256, reinterpret_cast<double*>(ri_lds), ra.N, K, D, ra.Rf, ra.x0, ra.F, ra.S0,
+                      ra.x, ra.zf, ra.fx, Qx, ra.yf);
+  wait_stores_performed();  // (S0 x, written through, is in place before the ticket is taken)
+  __syncthreads();
+  if (threadIdx.x == 0) last_sh = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  if (!last_sh) return;
+  if (threadIdx.x == 0) *ticket = 0u;  // (the next launch on this stream starts after this kernel has ended)
+  csr_small_body<true>(reinterpret_cast<int*>(ri_lds), nW, K, ncell, D, C, rho, wk, wi, wj, weta, Qx, zc, yc, ptr, ent, coef,
+                       pos_i, pos_j, gval, nr);
+}
+
+}  // namespace
+
+// The launch of scp_qp_reset(x0) + scp_qp_add_rows_at(rows) for small problems (scp_qp.hip: reset_impl keeps the host-side
+// state); *done = false: not eligible, nothing launched.  Qx: the slab S0 x goes to.  qp->rho is the QP's starting value.
+int scp_qp_reset_install_small(scp_qp* qp, const double* x0, int64_t n, const int64_t* rows, const double* pos_prev,
+                               const double* p0, const double* v0, double R, double* Qx, bool* done) {
+  *done = false;
+  const QpDev& d = qp->d;
+  const int K = qp->K;
+  if (n <= 0 || n > CSR1_MAX_ROWS || qp->N * K > CSR1_MAX_CELLS) return SCP_OK;
+  const int ncell = qp->N * K;
+  const double rho_c = qp->rho * qp->st.rho_col_scale;
+  const size_t lds = std::max((size_t)K * RESET_COLS * sizeof(double), (size_t)ncell * sizeof(int));
+  CsrNewRows nr{n, 0, rows, pos_prev, p0, v0, R, qp->h, qp->N, d.w_row, d.w_l};
+  ResetArgs ra{qp->N, qp->Rf, x0, d.F, d.S0, d.x, d.zf, d.fx, d.yf};
+  hipLaunchKernelGGL(reset_install_kernel, dim3((unsigned)scp_cdiv(qp->C, RESET_COLS)), dim3(1024), lds, qp->ctx->stream, ra, n,
+                     K, ncell, qp->D, qp->C, rho_c, d.w_k, d.w_i, d.w_j, d.w_eta, Qx, d.zc, d.yc, d.cell_ptr, d.ent_code,
+                     d.coef, d.pos_i, d.pos_j, d.gval, nr, qp->ctx->d_ticket + 2);  // ([0], [1]: the passes, the checks)
+  FUSED_LAUNCHED(qp);
+  qp->gval_rho_c = rho_c;
+  *done = true;
+  return SCP_OK;
+}
+
+namespace {
 // row values for the residual / certificate scatters
 __global__ __launch_bounds__(256) void csr_rowval_kernel(int64_t nW, int mode, double rho, const double* __restrict__ zc,
                                                           const double* __restrict__ yc, const double* __restrict__ vec,

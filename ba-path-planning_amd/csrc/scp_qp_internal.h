@@ -136,6 +136,10 @@ int scp_qp_cg1_prepare(scp_qp* qp);
 // lists + row values of all nW + n rows in ONE launch; *done = false: not eligible, nothing was launched
 int scp_qp_install_rows_small(scp_qp* qp, int64_t n, const int64_t* rows, const double* pos_prev, const double* p0,
                               const double* v0, double R, const double* Qx, bool* done);
+// small problems: scp_qp_reset(x0) AND the installation of the QP's first n rows in ONE launch (launch only: reset_impl in
+// scp_qp.hip keeps the host-side state); *done = false: not eligible, nothing was launched
+int scp_qp_reset_install_small(scp_qp* qp, const double* x0, int64_t n, const int64_t* rows, const double* pos_prev,
+                               const double* p0, const double* v0, double R, double* Qx, bool* done);
 constexpr int SCP_SYNC_WORDS = 16;  // u64: give-up word | scratch
 // Workgroups of a persistent launch: at most one per CU (all resident), and the exchange buffers below are sized for
 // exactly this many (+1: the fault-injection hook announces one workgroup more than it launches).

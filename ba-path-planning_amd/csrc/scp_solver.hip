@@ -245,12 +245,19 @@ int step_qp_round(scp_solver* s, StepState& t, const int64_t* rows, int64_t n, s
   scp_ctx* ctx = s->ctx;
   const int N = s->N, K = s->K, D = s->D;
   const bool first = t.rounds == 0;
+  bool rows_in = false;
   if (first) {
     SV_CHECK(scp_qp_update_settings(s->qp, &s->st));
-    SV_CHECK(scp_qp_reset(s->qp, t.acc_in));
-    if (s->rho_start > 0.0) SV_CHECK(scp_qp_set_rho(s->qp, s->rho_start));
+    if (t.row_free && s->rho_start <= 0.0 && n > 0 && n <= s->row_cap) {
+      // (reset and the QP's first rows in one launch when the problem is small; the two calls otherwise)
+      SV_CHECK(scp_qp_reset_add_rows_at(s->qp, t.acc_in, n, rows, s->pos_a, t.p0, t.v0, s->R));
+      rows_in = true;
+    } else {
+      SV_CHECK(scp_qp_reset(s->qp, t.acc_in));
+      if (s->rho_start > 0.0) SV_CHECK(scp_qp_set_rho(s->qp, s->rho_start));
+    }
   }
-  SV_CHECK(add_rows_growing(s, t, rows, n, !first));
+  if (!rows_in) SV_CHECK(add_rows_growing(s, t, rows, n, !first));
   t.nW += n;
   s->st.max_iter = std::max(t.max_iter - t.used, 1);
   SV_CHECK(scp_qp_update_settings(s->qp, &s->st));

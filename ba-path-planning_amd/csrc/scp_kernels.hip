@@ -509,6 +509,8 @@ struct PairUnroll {
   static constexpr int value = (USE_LDS && MODE != 2 /* MODE_VIOLATIONS: streaming reads, 4 in flight */) ? 2 : 4;
 };
 constexpr int PAIR_ROWS = PAIR_THREADS * PAIR_STEPS * 2;   // rows (= pairs at one k) per workgroup
+constexpr int PAIR_LDS_SLICE_BYTES = 16 * 1024;            // largest slice of a two-slice pass staged in LDS (beyond: L1/L2 path)
+constexpr int PAIR_LDS_Q_OFF = PAIR_LDS_SLICE_BYTES / 8;   // doubles between the P slice and the Q slice of a two-slice pass
 constexpr int SMALL_STEPS = 4;                             // ... of a small-problem pass: 2048 rows per workgroup, so that a
 constexpr int SMALL_ROWS = PAIR_THREADS * SMALL_STEPS * 2; // 128-agent problem still spreads over 200 compute units
 constexpr int64_t CMP1_MAX_WORDS = 64 * 1024;             // bitmap words (2 M rows) one workgroup compacts (compact_small_body)
@@ -522,6 +524,15 @@ enum PairMode { MODE_LINEARIZE = 0, MODE_CHECK = 1, MODE_VIOLATIONS = 2, MODE_VI
 //   l_r - (A x)_r = (R - dist) + eta.(Q_prev_i - Q_prev_j) - eta.(Q_new_i - Q_new_j) = (R - dist) - eta.(dP_i - dP_j),
 // dP = P_new - P_prev (the free motion c cancels): Q_tm holds dP.  Same LDS footprint as the linearise pass, no HBM
 // stream at all.
+
+// Work items of the linearisation pass of a large problem (pair_pass_kernel, ITEMS): up to MAX_CLASSES classes of items;
+// class c covers the time steps [k0[c], k0[c + 1]) in chunks of 2 * PAIR_THREADS * steps[c] rows, cpk[c] chunks per time
+// step, its items are numbered from item0[c] (time step major).  Classes are ordered by decreasing chunk size.
+struct PairItems {
+  static constexpr int MAX_CLASSES = 4;
+  int n_items, n_classes;
+  int item0[MAX_CLASSES], k0[MAX_CLASSES], cpk[MAX_CLASSES], steps[MAX_CLASSES];
+};
 
 struct PairArgs {
   int N, K, D;
@@ -537,6 +548,7 @@ struct PairArgs {
   uint32_t* mark;          // bits set by this pass: the bitmap itself (linearize) or a scratch map (violations)
   scp_pair_stats* stats;
   int ablate;            // developer switch (profiling build, env SCP_PAIR_ABLATE): 1 = skip the streaming stores, 2 = force no-LDS
+  PairItems items;       // MODE_LINEARIZE of a large problem: the work list of the persistent grid
   // ---- small problems (SMALL instantiations: the whole pass in ONE launch) --------------------------------------------
   const double* pos_a;   // [N][K][D] the pass's positions (select / check) or the linearisation point (violations)
   const double* pos_b;   // [N][K][D] new positions (violations), or NULL: derived from x_tm
@@ -614,6 +626,7 @@ __device__ inline void pair_advance_far(int& i, int& j, int N, int s, int64_t q_
 // pairwise kernel spent -> the clock the kernel actually ran at (MI355X_MICROARCH.md, in-kernel clock check)
 constexpr int SCP_PAIR_CLK_WGS = 4096;
 __device__ unsigned long long scp_pair_clk[2 * SCP_PAIR_CLK_WGS];
+__device__ unsigned long long scp_pair_t0[SCP_PAIR_CLK_WGS];  // absolute 100 MHz stamp at which the workgroup started
 // ... and the 100 MHz stamps of the LAST workgroup of a small-problem pass (thread 0), phase by phase (tools/small_pass_profile.py)
 __device__ unsigned long long scp_small_clk[16];
 #define SMALL_STAMP(i) do { if (threadIdx.x == 0) small_clk_local[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -642,24 +655,37 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
   SMALL_STAMP(0);
 #endif
   const int N = a.N;
-  const int k = blockIdx.y;
   const int64_t nq = a.q_end - a.q_begin;
-  const int64_t slice0 = (int64_t)k * nq;       // first local row of this k
-  const int64_t par = slice0 & 1;               // keep every thread's first row at an even local row id
   constexpr int STEPS = SMALL ? SMALL_STEPS : PAIR_STEPS;
-  constexpr int ROWS = PAIR_THREADS * STEPS * 2;
-  const int64_t c0 = (int64_t)blockIdx.x * ROWS - par;  // first local pair offset of this workgroup
   constexpr bool NEED_P = MODE != MODE_VIOLATIONS;
   constexpr bool NEED_Q = MODE != MODE_CHECK && MODE != MODE_SELECT;
   constexpr bool VIOL = MODE == MODE_VIOLATIONS || MODE == MODE_VIOL_RECOMPUTE;  // selects violated rows, reduces max violation
+  // ITEMS (the linearisation of large problems): a 1-D grid over a list of work items (time step k, chunk of 2 * PAIR_THREADS
+  // * steps rows) ordered LARGE -> SMALL (PairItems): the bulk in chunks of PAIR_STEPS steps, the last time steps in half-
+  // and quarter-size chunks, so that the compute units do not drain one by one while the last full-size workgroups finish
+  // (tools/pair_timeline.py: with equal chunks a quarter of the slot-time was idle, most of it in a 30 us tail).  A persistent
+  // grid taking the same items from a counter was measured too: 139 registers (3 workgroups per CU) or spills, slower.
+  constexpr bool ITEMS = MODE == MODE_LINEARIZE && !SMALL;
 
-  const double* P = NEED_P ? a.P_tm + (int64_t)k * N * D : nullptr;
-  const double* Q = NEED_Q ? a.Q_tm + (int64_t)k * N * D : nullptr;
   __shared__ uint32_t small_map_store[SMALL ? SMALL_ROWS / 32 : 1];
   __shared__ uint32_t small_map2_store[SMALL && MODE == MODE_VIOL_RECOMPUTE ? SMALL_ROWS / 32 : 1];
   uint32_t* const small_map = small_map_store;
   uint32_t* const small_map2 = small_map2_store;  // the speculative selection around the NEW positions (a.spec_rows)
-  const double* Pn = nullptr;                     // ... and those positions (third LDS slice)
+  const double thr = a.R - 0.01;  // scp.py:610
+  const double INF = __longlong_as_double(0x7FF0000000000000LL);
+  double my_min = INF, my_maxv = -INF;
+  unsigned long long my_first = 0xFFFFFFFFFFFFFFFFULL;
+
+  // one item: rows [chunk * rows_item - par, ... + rows_item) of time step k, rows_item = 2 * PAIR_THREADS * nsteps
+  auto run_item = [&](const int k, const int64_t chunk, const int nsteps_rt) {
+  const int nsteps = ITEMS ? nsteps_rt : STEPS;
+  const int64_t slice0 = (int64_t)k * nq;       // first local row of this k
+  const int64_t par = slice0 & 1;               // keep every thread's first row at an even local row id
+  const int ROWS = PAIR_THREADS * nsteps * 2;
+  const int64_t c0 = chunk * ROWS - par;  // first local pair offset of this item
+  const double* P = NEED_P ? a.P_tm + (int64_t)k * N * D : nullptr;
+  const double* Q = NEED_Q ? a.Q_tm + (int64_t)k * N * D : nullptr;
+  const double* Pn = nullptr;                     // (SMALL: the new positions, third LDS slice)
   if (SMALL) {
     if (threadIdx.x < SMALL_ROWS / 32) {
       small_map[threadIdx.x] = 0u;
@@ -676,7 +702,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
       if (MODE == MODE_SELECT && a.x_tm) {  // the pass's positions are the kinematics of the QP's solution (after QP#0)
         double pn, vn;
         kin_point(a.x_tm + c, C, k, a.h, a.p0[c], a.v0[c], pn, vn);
-        if (blockIdx.x == 0) {
+        if (chunk == 0) {
           store_coherent(a.pos_out + g, pn);
           store_coherent(a.x_out + g, a.x_tm[(int64_t)k * C + c]);
         }
@@ -690,7 +716,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
         if (a.x_tm) {
           double vn;
           kin_point(a.x_tm + c, C, k, a.h, a.p0[c], a.v0[c], pn, vn);
-          if (blockIdx.x == 0) {
+          if (chunk == 0) {
             store_coherent(a.pos_out + g, pn);
             store_coherent(a.x_out + g, a.x_tm[(int64_t)k * C + c]);
           }
@@ -706,26 +732,25 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
     P = sP;
     Q = sQ;
   } else if (USE_LDS) {
+    // two slices: the second one at a COMPILE-TIME distance from the first (the LDS path takes slices of <= 16 KB), so that
+    // P_i and Q_i are one address and an immediate offset -- one shift per index instead of a shift and two adds
     double* sP = lds;
-    double* sQ = lds + (NEED_P ? (int64_t)N * D : 0);
-    const int n2 = (N * D) >> 1;  // slices are 16-byte aligned: N*D*8 bytes from an aligned base, even count or tail
-    for (int t = threadIdx.x; t < n2; t += PAIR_THREADS) {
-      if (NEED_P) reinterpret_cast<double2*>(sP)[t] = reinterpret_cast<const double2*>(P)[t];
-      if (NEED_Q) reinterpret_cast<double2*>(sQ)[t] = reinterpret_cast<const double2*>(Q)[t];
+    double* sQ = lds + (NEED_P ? PAIR_LDS_Q_OFF : 0);
+    {
+      const int n2 = (N * D) >> 1;  // slices are 16-byte aligned: N*D*8 bytes from an aligned base, even count or tail
+      for (int t = threadIdx.x; t < n2; t += PAIR_THREADS) {
+        if (NEED_P) reinterpret_cast<double2*>(sP)[t] = reinterpret_cast<const double2*>(P)[t];
+        if (NEED_Q) reinterpret_cast<double2*>(sQ)[t] = reinterpret_cast<const double2*>(Q)[t];
+      }
+      if (((N * D) & 1) && threadIdx.x == 0) {
+        if (NEED_P) sP[N * D - 1] = P[N * D - 1];
+        if (NEED_Q) sQ[N * D - 1] = Q[N * D - 1];
+      }
+      __syncthreads();
     }
-    if (((N * D) & 1) && threadIdx.x == 0) {
-      if (NEED_P) sP[N * D - 1] = P[N * D - 1];
-      if (NEED_Q) sQ[N * D - 1] = Q[N * D - 1];
-    }
-    __syncthreads();
     P = sP;
     Q = sQ;
   }
-
-  const double thr = a.R - 0.01;  // scp.py:610
-  const double INF = __longlong_as_double(0x7FF0000000000000LL);
-  double my_min = INF, my_maxv = -INF;
-  unsigned long long my_first = 0xFFFFFFFFFFFFFFFFULL;
 
   // first pair of this thread
   const int64_t off0 = c0 + 2 * threadIdx.x;
@@ -748,7 +773,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
   auto body = [&](auto full_tag) {
   constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll 1
-  for (int s0 = 0; s0 < STEPS; s0 += PAIR_UNROLL) {
+  for (int s0 = 0; s0 < nsteps; s0 += PAIR_UNROLL) {
     double eta_v[PAIR_UNROLL][2][D];
     double l_v[PAIR_UNROLL][2];
     bool valid[PAIR_UNROLL][2];
@@ -993,6 +1018,20 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
   };
   if (full) body(std::true_type{});
   else body(std::false_type{});
+  };  // run_item
+
+  if constexpr (ITEMS) {  // one item per workgroup; the hardware dispatcher hands them out in order (large ones first)
+    const int item = blockIdx.x;
+    int c = 0;
+#pragma unroll
+    for (int t = 1; t < PairItems::MAX_CLASSES; ++t)
+      if (t < a.items.n_classes && item >= a.items.item0[t]) c = t;
+    const int j = item - a.items.item0[c];
+    const int kk = j / a.items.cpk[c];
+    run_item(a.items.k0[c] + kk, (int64_t)(j - kk * a.items.cpk[c]), a.items.steps[c]);
+  } else {
+    run_item((int)blockIdx.y, (int64_t)blockIdx.x, STEPS);
+  }
 
   // wavefront reductions, then one candidate per WORKGROUP; the global atomic is issued only when a relaxed
   // (L1-bypassing) read says the candidate would improve the result: same-address atomics retire at < 100 per
@@ -1312,6 +1351,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
     if (wg < (unsigned)SCP_PAIR_CLK_WGS) {
       scp_pair_clk[2 * wg] = __builtin_amdgcn_s_memtime() - clk_c0;
       scp_pair_clk[2 * wg + 1] = __builtin_amdgcn_s_memrealtime() - clk_t0;
+      scp_pair_t0[wg] = clk_t0;
     }
   }
 #endif
@@ -1438,7 +1478,9 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
   a.P_tm = P_tm;
   a.Q_tm = Q_tm;
   if (nq <= 0) return SCP_OK;
-  const size_t lds_bytes = (size_t)((MODE == MODE_LINEARIZE || MODE == MODE_VIOL_RECOMPUTE) ? 2 : 1) * N * D * sizeof(double);
+  const size_t slice_bytes = (size_t)N * D * sizeof(double);
+  const bool two_slices = MODE == MODE_LINEARIZE || MODE == MODE_VIOL_RECOMPUTE;  // (the second one PAIR_LDS_Q_OFF doubles in)
+  const size_t lds_bytes = two_slices ? PAIR_LDS_SLICE_BYTES + slice_bytes : slice_bytes;
   // the k-slice must start 16-byte aligned in global memory for the double2 staging loads: N*D even
 #ifdef SCP_PHASE_PROFILE  // developer build only (make prof): ablation switch of tools/pair_bench.py
   const char* abl = getenv("SCP_PAIR_ABLATE");
@@ -1448,9 +1490,49 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
 #endif
   // slices beyond 32 KB cut the occupancy below 5 workgroups per CU and the L1/L2 path wins (measured at 2048 x 50:
   // 5.43 TB/s without LDS, 4.74 with; at 1024 x 50, 32 KB: 5.0 with, 4.6 without)
-  const bool use_lds = lds_bytes <= 32 * 1024 && ((N * D) % 2 == 0) && !(a.ablate & 2);
+  const bool use_lds = slice_bytes <= (size_t)(two_slices ? 1 : 2) * PAIR_LDS_SLICE_BYTES && ((N * D) % 2 == 0) && !(a.ablate & 2);
   dim3 grid(scp_cdiv(nq + 1, PAIR_ROWS), K);
   dim3 block(PAIR_THREADS);
+  if constexpr (MODE == MODE_LINEARIZE) {
+    // work items ordered large -> small (PairItems): the bulk in chunks of PAIR_STEPS steps, then about one round of the
+    // resident workgroups in half-size and one in quarter-size chunks (whole time steps per class; measured sweep at
+    // 1024 x 50: profiles/r03_pair_tail_sweep.txt)
+    int per_cu = 0;
+    const void* kern = D == 2 ? (use_lds ? (const void*)pair_pass_kernel<2, MODE_LINEARIZE, true> : (const void*)pair_pass_kernel<2, MODE_LINEARIZE, false>)
+                              : (use_lds ? (const void*)pair_pass_kernel<3, MODE_LINEARIZE, true> : (const void*)pair_pass_kernel<3, MODE_LINEARIZE, false>);
+    SCP_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, PAIR_THREADS, use_lds ? lds_bytes : 0));
+    const int64_t slots = (int64_t)std::max(per_cu, 1) * ctx->n_cu;
+    PairItems& it = a.items;
+    it = PairItems{};
+    const int64_t big_per_k = scp_cdiv(nq + 1, PAIR_ROWS);
+    int nk_quarter = 0, nk_half = 0;
+    if (big_per_k * K > slots) {  // (otherwise every item is resident from the start)
+      nk_quarter = (int)((slots * (PAIR_ROWS / 4) + nq / 2) / nq);
+      nk_half = (int)((slots * (PAIR_ROWS / 2) + nq / 2) / nq);
+      if (nk_quarter + nk_half > K / 2) nk_quarter = nk_half = 0;  // few, long time steps: the classes cannot be cut this way
+    }
+#ifdef SCP_PHASE_PROFILE
+    if (const char* e = getenv("SCP_PAIR_TAIL")) {  // "half quarter": time steps cut in half- / quarter-size chunks
+      int h_ = 0, q_ = 0;
+      if (sscanf(e, "%d %d", &h_, &q_) == 2 && h_ >= 0 && q_ >= 0 && h_ + q_ < K) { nk_half = h_; nk_quarter = q_; }
+    }
+#endif
+    const int nk[3] = {K - nk_half - nk_quarter, nk_half, nk_quarter};
+    const int st[3] = {PAIR_STEPS, PAIR_STEPS / 2, PAIR_STEPS / 4};
+    int k0 = 0, item0 = 0;
+    for (int c = 0; c < 3; ++c) {
+      if (nk[c] <= 0) continue;
+      const int m = it.n_classes++;
+      it.item0[m] = item0;
+      it.k0[m] = k0;
+      it.steps[m] = st[c];
+      it.cpk[m] = (int)scp_cdiv(nq + 1, (int64_t)2 * PAIR_THREADS * st[c]);
+      item0 += nk[c] * it.cpk[m];
+      k0 += nk[c];
+    }
+    it.n_items = item0;
+    grid = dim3((unsigned)it.n_items, 1);
+  }
   if (ctx->timing) SCP_HIP_CHECK(ctx, hipEventRecord(ctx->pair_ev0, ctx->stream));
 #define SCP_LAUNCH_PAIR(DD, LDS)                                                                        \
   hipLaunchKernelGGL((pair_pass_kernel<DD, MODE, LDS>), grid, block, (LDS) ? lds_bytes : 0, ctx->stream, a)
@@ -1474,6 +1556,10 @@ static int launch_pair_pass(scp_ctx* ctx, PairArgs& a, const double* pos_ref_lay
 extern "C" int scp_debug_small_clocks(unsigned long long* out, int n) {
   if (n > 16) n = 16;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(scp_small_clk), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+extern "C" int scp_debug_pair_starts(unsigned long long* out, int n) {
+  if (n > SCP_PAIR_CLK_WGS) n = SCP_PAIR_CLK_WGS;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(scp_pair_t0), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }
 extern "C" int scp_debug_pair_clocks(unsigned long long* out, int n) {
   if (n > 2 * SCP_PAIR_CLK_WGS) n = 2 * SCP_PAIR_CLK_WGS;

@@ -805,7 +805,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
       }
     }
     uint32_t marked[PAIR_UNROLL];
-    if (MODE == MODE_VIOL_RECOMPUTE) {
+    if (MODE == MODE_VIOL_RECOMPUTE && !(FULL && !SMALL)) {  // (interior workgroups of large problems: read only when a row is violated)
 #pragma unroll
       for (int u = 0; u < PAIR_UNROLL; ++u) {
         const int64_t lrA = slice0 + off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS);
@@ -844,9 +844,36 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
     // STREAM (interior workgroups of the linearisation): the rare events of a row -- a degenerate pair (scp.py:503), a
     // distance below R - 0.01 (scp.py:610) -- are only FLAGGED in the row loop and handled behind one branch per group
     // afterwards; the loop itself runs pair_row_regular (no selects).  Same values: the repair calls pair_row.
-    constexpr bool STREAM = MODE == MODE_LINEARIZE && FULL;
+    constexpr bool STREAM = (MODE == MODE_LINEARIZE || ((MODE == MODE_SELECT || MODE == MODE_CHECK) && !SMALL)) && FULL;
+    // STREAMV: the same for the recomputing violations pass -- l - A x by the regular formulas, the group's largest value
+    // decides whether any row can be violated (only then the membership bits are read), a possible degenerate pair sends
+    // the whole group through the exact formulas again
+    constexpr bool STREAMV = MODE == MODE_VIOL_RECOMPUTE && !SMALL && FULL;
+    double viol_v[PAIR_UNROLL][2];
+    double viol_max = -INF;
     double raw_v[PAIR_UNROLL][2];
     double raw_min = INF;  // over the group's rows: ONE comparison per group and event decides whether any row needs a closer look
+    // UNIFORM i (slices read through L1 / L2, i.e. more than 1024 agents): a wave's 128 consecutive pairs of a step mostly
+    // lie in ONE row of the triangle (rows are ~N / 2 long), so agent i's points are the same for all 64 lanes: they come
+    // through the SCALAR cache into SGPRs (one s_load per point and step instead of 64 lanes x 16 B through the vector L1,
+    // which is what bounds these passes: 48 of its 64 B / clk / CU in the violations pass at 4096 agents).  Pairs are
+    // consecutive, so "lane 63's second row has lane 0's i" is the whole test; other waves take the per-lane loads.
+    constexpr bool UNI_OK = !USE_LDS && !SMALL && MODE != MODE_VIOLATIONS;
+    int iu[PAIR_UNROLL];
+    bool uni = UNI_OK;
+    if (UNI_OK) {
+#pragma unroll
+      for (int u = 0; u < PAIR_UNROLL; ++u) {
+        iu[u] = __builtin_amdgcn_readfirstlane(pi_[u][0]);
+        uni = uni && __builtin_amdgcn_readlane(pi_[u][1], 63) == iu[u];
+      }
+    }
+    auto row_loop = [&](auto uni_tag) {
+    constexpr bool UNI = decltype(uni_tag)::value;
+    auto load_i = [&](const double* base, int i, int u) -> Pt<D> {
+      if constexpr (UNI) return load_pt_uniform<D>(base, iu[u]);
+      else return load_pt<D>(base, i);
+    };
 #pragma unroll
     for (int u = 0; u < PAIR_UNROLL; ++u) {
 #pragma unroll
@@ -854,14 +881,26 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
         const int i = pi_[u][e], j = pj_[u][e];
         sel[u][e] = false;
         if (STREAM) {
-          const Pt<D> Pi = load_pt<D>(P, i), Pj = load_pt<D>(P, j);
+          const Pt<D> Pi = load_i(P, i, u), Pj = load_pt<D>(P, j);
           const PairGeom<D> g = pair_geom<D>(Pi, Pj);
           raw_v[u][e] = g.raw;
           raw_min = fmin(raw_min, g.raw);
-          const Pt<D> Qi = load_pt<D>(Q, i), Qj = load_pt<D>(Q, j);
-          pair_row_regular<D>(g, Qi, Qj, a.R, eta_v[u][e], l_v[u][e]);
+          if (MODE == MODE_LINEARIZE) {
+            const Pt<D> Qi = load_i(Q, i, u), Qj = load_pt<D>(Q, j);
+            pair_row_regular<D>(g, Qi, Qj, a.R, eta_v[u][e], l_v[u][e]);
+          }
+        } else if (STREAMV) {
+          const Pt<D> Pi = load_i(P, i, u), Pj = load_pt<D>(P, j);
+          const PairGeom<D> g = pair_geom<D>(Pi, Pj);
+          raw_min = fmin(raw_min, g.raw);
+          const Pt<D> Di = load_i(Q, i, u), Dj = load_pt<D>(Q, j);  // dP = P_new - P_prev
+          double qd = 0.0;
+#pragma unroll
+          for (int d = 0; d < D; ++d) qd = fma(g.diff[d] * g.inv, Di.v[d] - Dj.v[d], qd);
+          viol_v[u][e] = (a.R - g.raw) - qd;  // l_r - (A x)_r of a regular pair
+          viol_max = fmax(viol_max, viol_v[u][e]);
         } else if (MODE != MODE_VIOLATIONS) {
-          const Pt<D> Pi = load_pt<D>(P, i), Pj = load_pt<D>(P, j);
+          const Pt<D> Pi = load_i(P, i, u), Pj = load_pt<D>(P, j);
           const PairGeom<D> g = pair_geom<D>(Pi, Pj);
           const double* diff = g.diff;
           const bool deg = g.deg;
@@ -875,7 +914,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
             }
           }
           if (MODE == MODE_LINEARIZE) {
-            const Pt<D> Qi = load_pt<D>(Q, i), Qj = load_pt<D>(Q, j);
+            const Pt<D> Qi = load_i(Q, i, u), Qj = load_pt<D>(Q, j);
             double dist;
             pair_row<D>(g, Qi, Qj, a.R, eta_v[u][e], l_v[u][e], dist);
             sel[u][e] = valid[u][e] && ((dist - a.R) < a.margin);
@@ -885,7 +924,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
             sel[u][e] = valid[u][e] && ((dist - a.R) < a.margin);
           }
           if (MODE == MODE_VIOL_RECOMPUTE) {
-            const Pt<D> Di = load_pt<D>(Q, i), Dj = load_pt<D>(Q, j);  // dP = P_new - P_prev
+            const Pt<D> Di = load_i(Q, i, u), Dj = load_pt<D>(Q, j);  // dP = P_new - P_prev
             const double dist = deg ? 1.0 : raw;
             double qd = 0.0;
 #pragma unroll
@@ -917,10 +956,13 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
         any_sel |= sel[u][e];
       }
     }
+    };  // row_loop
+    if (UNI_OK && uni) row_loop(std::true_type{});
+    else row_loop(std::false_type{});
     if (STREAM) {
       my_min = fmin(my_min, raw_min);
       // (x -> x - R is monotone, so "some row passes the selection test" implies "the smallest distance passes it")
-      if ((raw_min - a.R) < a.margin) {
+      if (MODE != MODE_CHECK && (raw_min - a.R) < a.margin) {
 #pragma unroll
         for (int u = 0; u < PAIR_UNROLL; ++u)
 #pragma unroll
@@ -940,7 +982,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
               my_first = g_ < my_first ? g_ : my_first;
             }
       }
-      if (raw_min < 2e-6) {  // (a degenerate pair has dist^2 < 1e-12: the exact test is g.deg below)
+      if (MODE != MODE_CHECK && raw_min < 2e-6) {  // (a degenerate pair has dist^2 < 1e-12: the exact test is g.deg below)
         any_sel = false;
 #pragma unroll
         for (int u = 0; u < PAIR_UNROLL; ++u)
@@ -949,12 +991,48 @@ __global__ __launch_bounds__(PAIR_THREADS) void pair_pass_kernel(PairArgs a) {
             const int i = pi_[u][e], j = pj_[u][e];
             const PairGeom<D> g = pair_geom<D>(load_pt<D>(P, i), load_pt<D>(P, j));
             if (g.deg) {
-              double dist;
-              pair_row<D>(g, load_pt<D>(Q, i), load_pt<D>(Q, j), a.R, eta_v[u][e], l_v[u][e], dist);
+              double dist = 1.0;  // scp.py:503-507
+              if (MODE == MODE_LINEARIZE)
+                pair_row<D>(g, load_pt<D>(Q, i), load_pt<D>(Q, j), a.R, eta_v[u][e], l_v[u][e], dist);
               sel[u][e] = (dist - a.R) < a.margin;
             }
             any_sel |= sel[u][e];
           }
+      }
+    }
+    if (STREAMV) {
+      if (raw_min < 2e-6) {  // a degenerate pair somewhere in the group: every row again, by the formulas that know about it
+        viol_max = -INF;
+#pragma unroll
+        for (int u = 0; u < PAIR_UNROLL; ++u)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int i = pi_[u][e], j = pj_[u][e];
+            const PairGeom<D> g = pair_geom<D>(load_pt<D>(P, i), load_pt<D>(P, j));
+            const Pt<D> Di = load_pt<D>(Q, i), Dj = load_pt<D>(Q, j);
+            const double dist = g.deg ? 1.0 : g.raw;
+            double qd = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+              const double e_d = g.deg ? (d == 0 ? 1.0 : 0.0) : g.diff[d] * g.inv;
+              qd = fma(e_d, Di.v[d] - Dj.v[d], qd);
+            }
+            viol_v[u][e] = (a.R - dist) - qd;
+            viol_max = fmax(viol_max, viol_v[u][e]);
+          }
+      }
+      my_maxv = fmax(my_maxv, viol_max);
+      if (viol_max > a.margin) {  // some row of the group is violated: which ones, and are they in the working set already?
+#pragma unroll
+        for (int u = 0; u < PAIR_UNROLL; ++u) {
+          const int64_t lrA = slice0 + off0 + (int64_t)(s0 + u) * (2 * PAIR_THREADS);
+          const uint32_t mk = (a.bitmap[lrA >> 5] >> (lrA & 31)) & 3u;  // (both rows of the step share one word: lrA is even)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            sel[u][e] = (viol_v[u][e] > a.margin) && !((mk >> e) & 1u);
+            any_sel |= sel[u][e];
+          }
+        }
       }
     }
 

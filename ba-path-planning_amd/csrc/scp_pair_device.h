@@ -67,6 +67,19 @@ __device__ inline Pt<D> load_pt(const double* base, int idx) {
   return r;
 }
 
+// The same point through the SCALAR cache, for an index that is the same in all lanes of the wave (the caller made it so with
+// readfirstlane): the result lives in SGPRs.  Constant address space = "not written while this kernel runs" (the slices
+// are the prep kernel's output).
+template <int D>
+__device__ inline Pt<D> load_pt_uniform(const double* base, int idx_uniform) {
+  typedef const double __attribute__((address_space(4))) cdouble;
+  cdouble* q = (cdouble*)(uintptr_t)(base + (int64_t)D * idx_uniform);
+  Pt<D> r;
+#pragma unroll
+  for (int d = 0; d < D; ++d) r.v[d] = q[d];
+  return r;
+}
+
 // Geometry of one pair at one time step and the compact row derived from it -- the arithmetic of scp.py:498-509, :543-549.
 // Shared by the pairwise passes and by add_rows_at_kernel (the row-free loop recomputes the selected rows with it): one
 // definition, the same bits.

@@ -99,7 +99,8 @@ def test_linearize_vs_reference(ctx, golden_dir, name):
 
 @pytest.mark.parametrize("N,K,D,seed", [(2, 5, 2, 1), (7, 13, 2, 2), (33, 21, 3, 3), (96, 50, 2, 4), (65, 50, 3, 5),
                                         (130, 17, 2, 6), (300, 7, 2, 7), (257, 5, 3, 8), (256, 4, 2, 9),
-                                        (700, 10, 2, 10)])  # 2.4 M rows: the three-launch compaction (maps beyond 64 K words)
+                                        (700, 10, 2, 10),  # 2.4 M rows: the three-launch compaction (maps beyond 64 K words)
+                                        (1100, 3, 2, 11), (700, 3, 3, 12)])  # slices beyond 16 KB: the L1 / L2 path (scalar loads of agent i)
 def test_linearize_vs_oracle_synthetic(ctx, N, K, D, seed):
     from path_planning import _hip
 
@@ -151,7 +152,8 @@ def test_linearize_pair_range_shards(ctx, N, K, cuts):
 
 
 @pytest.mark.parametrize("N,K,D,seed,cut", [(2, 5, 2, 1, None), (33, 21, 3, 3, None), (96, 50, 2, 4, None), (65, 50, 3, 5, None),
-                                             (300, 7, 2, 7, None), (700, 10, 2, 10, None), (130, 17, 2, 6, (1000, 6001))])
+                                             (300, 7, 2, 7, None), (700, 10, 2, 10, None), (130, 17, 2, 6, (1000, 6001)),
+                                             (1100, 3, 2, 11, None), (700, 3, 3, 12, None)])
 def test_row_free_linearisation_is_bit_identical(ctx, N, K, D, seed, cut):
     """scp_select_pairs + scp_qp_add_rows_at (the row-free loop: no eta / l planes) against scp_linearize_pairs + gather +
     scp_qp_add_rows: the same selected rows, bitmap and a8 statistics, and BITWISE the same working rows (eta, l, z_c)."""
@@ -188,6 +190,49 @@ def test_row_free_linearisation_is_bit_identical(ctx, N, K, D, seed, cut):
         np.testing.assert_array_equal(got["at"][k], got["gather"][k], err_msg=k)
 
 
+@pytest.mark.parametrize("N,K,D", [(300, 4, 2), (1100, 3, 2)])
+def test_degenerate_pairs_in_interior_workgroups(ctx, N, K, D):
+    """Coincident agents whose rows lie in INTERIOR workgroups of every pass (the streaming form: regular formulas for all
+    rows, the degenerate rule of scp.py:503-507 applied behind the group's smallest distance) -- LDS path and L1 / L2 path."""
+    from path_planning import _hip
+
+    prob, acc = synth(N, K, D, 31)
+    twins = [(5, 100), (150, 200), (N - 40, N - 3)]
+    p0, v0 = prob.p0.copy(), prob.v0.copy()
+    acc = acc.reshape(N, K, D).copy()
+    for a, b in twins:
+        p0[b], v0[b], acc[b] = p0[a], v0[a], acc[a]
+    prob = so.make_problem(N, K * prob.h + 1e-9, prob.h, prob.R, np.concatenate([prob.pos_min, prob.pos_max]), p0, prob.pf, v0, prob.vf)
+    pos, _ = so.kinematics(prob, acc)
+    eta_o, l_o, dist_o = so.linearize_pairs(prob, pos)
+    assert np.sum(dist_o == 1.0) >= len(twins) * K  # (the rule sets dist := 1 for them)
+    pos_t, p0_t, v0_t = ctx.tensor(pos), ctx.tensor(prob.p0), ctx.tensor(prob.v0)
+    pp = _hip.PairPass(ctx, N, K, D, prob.R, prob.h)
+    rows, min_dist, first = pp.linearize(pos_t, p0_t, v0_t, 0.3)
+    np.testing.assert_allclose(pp.l_rows().cpu().numpy(), l_o, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(pp.eta_rows().cpu().numpy(), eta_o, rtol=0, atol=1e-13)
+    want = np.nonzero(dist_o - prob.R < 0.3)[0]
+    np.testing.assert_array_equal(np.sort(rows.cpu().numpy()), want)
+    iu, ju = so.pair_index(N)
+    q_first = int(np.nonzero((iu == twins[0][0]) & (ju == twins[0][1]))[0][0])
+    assert min_dist == 0.0 and first <= q_first  # (the first twin pair at k = 0, unless a closer-than-R pair precedes it)
+    sel = _hip.PairPass(ctx, N, K, D, prob.R, prob.h)
+    rows_s, md_s, fv_s = sel.select(pos_t, 0.3)
+    np.testing.assert_array_equal(rows_s.cpu().numpy(), rows.cpu().numpy())
+    assert md_s == min_dist and fv_s == first
+    md_c, fv_c, _, _ = ctx.check_avoidance(N, K, D, prob.R, pos_t)
+    assert md_c == min_dist and fv_c == first
+    # the recomputing violations pass at a displaced point
+    x = acc + 0.2 * np.random.default_rng(32).standard_normal(acc.shape)
+    pos_new, _ = so.kinematics(prob, x)
+    viol = l_o - so.collision_apply(prob, eta_o, x.ravel())
+    W = set(rows.cpu().numpy().tolist())
+    want_v = sorted(r for r in np.nonzero(viol > 1e-6)[0].tolist() if r not in W)
+    new_rows, max_v = pp.violations(ctx.tensor(pos_new), p0_t, v0_t, 1e-6, recompute=True)
+    assert sorted(new_rows.cpu().numpy().tolist()) == want_v
+    assert abs(max_v - viol.max()) < 1e-11
+
+
 def test_degenerate_pair(ctx):
     from path_planning import _hip
 
@@ -214,7 +259,8 @@ def test_degenerate_pair(ctx):
 
 @pytest.mark.parametrize("recompute", [True, False])
 @pytest.mark.parametrize("N,K,D,seed", [(9, 12, 2, 21), (40, 50, 2, 22), (30, 25, 3, 23), (280, 6, 2, 24), (270, 3, 3, 25),
-                                        (700, 10, 2, 26)])  # (the last one: three-launch compaction, incl. its overflow path)
+                                        (700, 10, 2, 26),  # (three-launch compaction, incl. its overflow path)
+                                        (1100, 3, 2, 27), (700, 3, 3, 28)])  # (the L1 / L2 path)
 def test_collision_violations_pass(ctx, N, K, D, seed, recompute):
     """Both forms of the pass: recomputing eta / l from the linearisation point (scp_collision_violations_at, the
     default: nothing streamed from HBM) and reading the stored rows (scp_collision_violations)."""

@@ -47,6 +47,16 @@ head -12 $OUT/phase_profile_lean_n4096.txt
 timeout -k 10 300 python3 tools/step_time.py 128x2 1024x2 1024x2x4 2048x2 2048x2x4 2056x2 3000x2 4096x2 64x3 512x3 1024x3 1100x3 2048x3 > $OUT/step_time.txt 2>&1; cat $OUT/step_time.txt
 timeout -k 10 60 tools/bin/membw > $OUT/membw.txt 2>&1
 SCP_HIP_LIB=$R/ba-path-planning_amd/lib/libscp_hip_prof.so timeout -k 10 200 python3 tools/pair_context.py --agents 1024 > $OUT/pair_context_clock_1024.txt 2>&1; cat $OUT/pair_context_clock_1024.txt
+echo "== linearisation kernel: workgroup timeline (equal chunks vs the large -> small item list), without its stores, SQ counters"
+for T in "0 0" ""; do
+  F=$OUT/pair_timeline_$( [ -z "$T" ] && echo items || echo equal_chunks ).txt
+  if [ -z "$T" ]; then SCP_HIP_LIB=$R/ba-path-planning_amd/lib/libscp_hip_prof.so timeout -k 10 100 python3 tools/pair_timeline.py --reps 8 > $F 2>&1
+  else SCP_PAIR_TAIL="$T" SCP_HIP_LIB=$R/ba-path-planning_amd/lib/libscp_hip_prof.so timeout -k 10 100 python3 tools/pair_timeline.py --reps 8 > $F 2>&1; fi
+done
+SCP_PAIR_ABLATE=1 SCP_HIP_LIB=$R/ba-path-planning_amd/lib/libscp_hip_prof.so timeout -k 10 100 python3 tools/pair_timeline.py --reps 4 > $OUT/pair_timeline_items_nostores.txt 2>&1
+grep "launch [4-7]" $OUT/pair_timeline_equal_chunks.txt $OUT/pair_timeline_items.txt | cut -c1-160
+timeout -k 10 200 python3 tools/pair_bench.py --reps 5 --agents 4096 > $OUT/pair_bench_n4096.txt 2>&1
+timeout -k 10 200 python3 tools/pair_bench.py --reps 5 --agents 1024 > $OUT/pair_bench_n1024.txt 2>&1
 echo "== 2-rank rehearsals on this one GPU (gloo, host-staged exchanges)"
 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29711 bench.py --gpus 2 --share-gpu --backend gloo --steps 10 --warmup 2 --no-cpu-baseline 2> $OUT/rehearsal_1024.err | grep '^{"metric"' > $OUT/rehearsal_2ranks_gloo_n1024.json
 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29712 bench.py --agents 4096 --gpus 2 --share-gpu --backend gloo --steps 3 --warmup 1 --no-cpu-baseline 2> $OUT/rehearsal_4096.err | grep '^{"metric"' > $OUT/rehearsal_2ranks_gloo_n4096.json

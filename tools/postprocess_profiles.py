@@ -38,6 +38,9 @@ COPIES = {
     "rehearsal_2ranks_gloo_n1024.json": "rehearsal_2ranks_gloo_n1024.json",
     "rehearsal_2ranks_gloo_n4096.json": "rehearsal_2ranks_gloo_n4096.json",
     "pair_context_clock_1024.txt": "pair_context_clock_1024.txt", "membw.txt": "membw.txt",
+    "pair_timeline_equal_chunks.txt": "pair_timeline_equal_chunks.txt", "pair_timeline_items.txt": "pair_timeline_items.txt",
+    "pair_timeline_items_nostores.txt": "pair_timeline_items_nostores.txt",
+    "pair_bench_n4096.txt": "pair_bench_n4096.txt", "pair_bench_n1024.txt": "pair_bench_n1024.txt",
 }
 for a, b in COPIES.items():
     pa = os.path.join(src, a)
@@ -47,7 +50,7 @@ for a, b in COPIES.items():
         print("missing:", a)
 
 OURS = ("pair_pass_kernel", "cg1_", "add_rows_at", "qp0_col", "compact_", "csr_", "pair_prep", "qp_reset", "kinematics", "rows_value",
-        "add_rows", "spd_inverse", "gemm_f64", "pack_operands", "build_hf", "rel_step", "check_done")
+        "add_rows", "reset_install", "spd_inverse", "gemm_f64", "pack_operands", "build_hf", "rel_step", "check_done")
 
 
 def reduce_pmc(name_in, name_out):

@@ -151,6 +151,51 @@ def test_linearize_pair_range_shards(ctx, N, K, cuts):
     np.testing.assert_array_equal(np.sort(np.concatenate(got)), np.nonzero(dist_o - prob.R < 0.7)[0])
 
 
+@pytest.mark.parametrize("N,K,D", [(1024, 50, 2), (1300, 12, 2)])
+def test_linearize_item_list_shards_tile_the_full_pass(ctx, N, K, D):
+    """Large problems: the linearisation grid is a list of work items in up to three chunk sizes (whole time steps per size,
+    large first).  Pair-range shards with odd cuts, each with its OWN item list, must reproduce the rows, the selection and
+    the statistics of the full pass bit for bit (LDS path at 1024 agents, L1 / L2 path with scalar loads at 1300); the full
+    pass itself is held against the oracle on a sample of rows."""
+    import torch
+    from path_planning import _hip
+
+    prob, acc = synth(N, K, D, 41)
+    pos, _ = so.kinematics(prob, acc)
+    pos_t, p0, v0 = ctx.tensor(pos), ctx.tensor(prob.p0), ctx.tensor(prob.v0)
+    pairs = prob.pairs
+    full = _hip.PairPass(ctx, N, K, D, prob.R, prob.h)
+    rows_f, md_f, fv_f = full.linearize(pos_t, p0, v0, 0.4)
+    eta_f = full.eta_rows().reshape(K, pairs, D)
+    l_f = full.l_rows().reshape(K, pairs)
+    cuts = [0, 100001, pairs // 2 + 1, pairs]
+    got, mds, fvs = [], [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        pp = _hip.PairPass(ctx, N, K, D, prob.R, prob.h, a, b)
+        rows, md, fv = pp.linearize(pos_t, p0, v0, 0.4)
+        assert torch.equal(pp.l_rows().reshape(K, b - a), l_f[:, a:b])
+        assert torch.equal(pp.eta_rows().reshape(K, b - a, D), eta_f[:, a:b])
+        got.append(rows)
+        mds.append(md)
+        fvs.append(fv)
+    assert torch.equal(torch.sort(torch.cat(got)).values, rows_f)
+    assert min(mds) == md_f and min(fvs) == fv_f
+    # a sample of rows of the full pass against the oracle's arithmetic (scp.py:498-509, :543-549)
+    rng = np.random.default_rng(42)
+    iu, ju = so.pair_index(N)
+    ks, qs = rng.integers(0, K, 4000), rng.integers(0, pairs, 4000)
+    h = prob.h
+    for k, q in zip(ks[:4000], qs[:4000]):
+        i, j = int(iu[q]), int(ju[q])
+        diff = pos[i, k] - pos[j, k]
+        dist = float(np.linalg.norm(diff))
+        eta = diff / dist
+        ci = prob.p0[i] + (k * h) * prob.v0[i]
+        cj = prob.p0[j] + (k * h) * prob.v0[j]
+        l = prob.R + (eta @ diff - dist) - eta @ (ci - cj)
+        assert abs(float(l_f[k, q]) - l) < 1e-12 and np.abs(eta_f[k, q].cpu().numpy() - eta).max() < 1e-13
+
+
 @pytest.mark.parametrize("N,K,D,seed,cut", [(2, 5, 2, 1, None), (33, 21, 3, 3, None), (96, 50, 2, 4, None), (65, 50, 3, 5, None),
                                              (300, 7, 2, 7, None), (700, 10, 2, 10, None), (130, 17, 2, 6, (1000, 6001)),
                                              (1100, 3, 2, 11, None), (700, 3, 3, 12, None)])

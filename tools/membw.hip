@@ -37,6 +37,53 @@ __global__ void wr_chunk2d(double* a, double* b, double* c, size_t nq, int steps
     }
   }
 }
+// pattern D: the same 2-D grid and the same 16 steps per workgroup, but the workgroups of a time step INTERLEAVE at 4 KB: step s of
+// workgroup x writes rows x * 512 + s * (X * 512) -- at any moment the resident workgroups write a few compact windows
+// instead of one 64 KB stream each
+__global__ void wr_inter2d(double* a, double* b, double* c, size_t nq, int steps) {
+  size_t slice0 = (size_t)blockIdx.y * nq;
+  for (int s = 0; s < steps; ++s) {
+    size_t o = ((size_t)s * gridDim.x + blockIdx.x) * 512 + 2 * threadIdx.x;
+    if (o + 1 < nq) {
+      size_t r = slice0 + o;
+      double2 v = make_double2((double)r, 1.0);
+      *reinterpret_cast<double2*>(a + r) = v;
+      *reinterpret_cast<double2*>(b + r) = v;
+      *reinterpret_cast<double2*>(c + r) = v;
+    }
+  }
+}
+// pattern E: gangs of G workgroups interleave (stride G * 512 rows between the steps of a workgroup)
+__global__ void wr_gang2d(double* a, double* b, double* c, size_t nq, int steps, int G) {
+  size_t slice0 = (size_t)blockIdx.y * nq;
+  size_t gang = blockIdx.x / G, g = blockIdx.x % G;
+  for (int s = 0; s < steps; ++s) {
+    size_t o = gang * (size_t)G * 512 * steps + ((size_t)s * G + g) * 512 + 2 * threadIdx.x;
+    if (o + 1 < nq) {
+      size_t r = slice0 + o;
+      double2 v = make_double2((double)r, 1.0);
+      *reinterpret_cast<double2*>(a + r) = v;
+      *reinterpret_cast<double2*>(b + r) = v;
+      *reinterpret_cast<double2*>(c + r) = v;
+    }
+  }
+}
+// pattern F: gangs of G workgroups interleave PIECES of P consecutive steps (P * 512 rows)
+__global__ void wr_gangp2d(double* a, double* b, double* c, size_t nq, int steps, int G, int P) {
+  size_t slice0 = (size_t)blockIdx.y * nq;
+  size_t gang = blockIdx.x / G, g = blockIdx.x % G;
+  for (int s = 0; s < steps; ++s) {
+    size_t piece = s / P, in = s % P;
+    size_t o = gang * (size_t)G * 512 * steps + ((piece * G + g) * P + in) * 512 + 2 * threadIdx.x;
+    if (o + 1 < nq) {
+      size_t r = slice0 + o;
+      double2 v = make_double2((double)r, 1.0);
+      *reinterpret_cast<double2*>(a + r) = v;
+      *reinterpret_cast<double2*>(b + r) = v;
+      *reinterpret_cast<double2*>(c + r) = v;
+    }
+  }
+}
 typedef double d2_t __attribute__((ext_vector_type(2)));
 // pattern C with non-temporal stores
 __global__ void wr_chunk2d_nt(double* a, double* b, double* c, size_t nq, int steps) {
@@ -74,6 +121,15 @@ int main() {
   time("wr_chunk2d", [&] { hipLaunchKernelGGL(wr_chunk2d, dim3((nq + 4095) / 4096, K), dim3(256), 0, 0, a, b, c, nq, 8); });
   time("wr_chunk2d16", [&] { hipLaunchKernelGGL(wr_chunk2d, dim3((nq + 8191) / 8192, K), dim3(256), 0, 0, a, b, c, nq, 16); });
   time("wr_c2d16_nt", [&] { hipLaunchKernelGGL(wr_chunk2d_nt, dim3((nq + 8191) / 8192, K), dim3(256), 0, 0, a, b, c, nq, 16); });
+  time("wr_inter2d16", [&] { hipLaunchKernelGGL(wr_inter2d, dim3((nq + 8191) / 8192, K), dim3(256), 0, 0, a, b, c, nq, 16); });
+  time("wr_gang2_16", [&] { hipLaunchKernelGGL(wr_gang2d, dim3((nq + 8191) / 8192, K), dim3(256), 0, 0, a, b, c, nq, 16, 2); });
+  time("wr_gang4_16", [&] { hipLaunchKernelGGL(wr_gang2d, dim3((nq + 8191) / 8192, K), dim3(256), 0, 0, a, b, c, nq, 16, 4); });
+  time("wr_gang8_16", [&] { hipLaunchKernelGGL(wr_gang2d, dim3((nq + 8191) / 8192, K), dim3(256), 0, 0, a, b, c, nq, 16, 8); });
+  time("wr_g8_p2", [&] { hipLaunchKernelGGL(wr_gangp2d, dim3((nq + 8191) / 8192, K), dim3(256), 0, 0, a, b, c, nq, 16, 8, 2); });
+  time("wr_g8_p4", [&] { hipLaunchKernelGGL(wr_gangp2d, dim3((nq + 8191) / 8192, K), dim3(256), 0, 0, a, b, c, nq, 16, 8, 4); });
+  time("wr_g64_p2", [&] { hipLaunchKernelGGL(wr_gangp2d, dim3((nq + 8191) / 8192, K), dim3(256), 0, 0, a, b, c, nq, 16, 64, 2); });
+  time("wr_g64_p4", [&] { hipLaunchKernelGGL(wr_gangp2d, dim3((nq + 8191) / 8192, K), dim3(256), 0, 0, a, b, c, nq, 16, 64, 4); });
+  time("wr_g16_p1", [&] { hipLaunchKernelGGL(wr_gangp2d, dim3((nq + 8191) / 8192, K), dim3(256), 0, 0, a, b, c, nq, 16, 16, 1); });
   time("wr_chunk1", [&] { hipLaunchKernelGGL(wr_chunk, dim3((n + 511) / 512), dim3(256), 0, 0, a, b, c, n, 1); });
   time("rd_linear", [&] { hipLaunchKernelGGL(rd_linear, dim3((n / 2 + 255) / 256), dim3(256), 0, 0, (const double2*)a, (const double2*)b, (const double2*)c, n / 2, out); });
   return 0;

@@ -267,6 +267,8 @@ class Context:
         per complete solve, the kernel times in the records then read 0 and solve_ms is host wall clock),
         "single_launch_passes" (one-launch pairwise passes for small problems)"""
         self.check(self.lib.scp_ctx_set_option(self.h, key.encode(), int(value)))
+        if key != "kernel_timing":  # (every SCP object sets that one itself; a context with other switches moved is not pooled)
+            self.options_changed = True
 
     def set_timing(self, on):
         self.set_option("kernel_timing", 1 if on else 0)

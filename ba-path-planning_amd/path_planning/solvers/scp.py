@@ -13,17 +13,51 @@ Differences to the reference that a caller can observe (INTEGRATION.md has the f
     2.6e9-non-zero CSC matrix; ``C_jerk/C_acc/C_vel/C_pos`` are not materialised (they stay None);
   * new keyword-only arguments: ``dim`` (2 or 3), ``device``, ``qp_settings``, ``working_set_margin``,
     ``feasibility_tol``, ``max_rounds``, ``refresh_feasibility``, ``polish``/``polish_eps``, ``native``, ``row_free``, ``carry_rho``, ``kernel_timing``,
-    ``qp_row_capacity``, ``verbose``, ``rank``/``world_size``/``group`` (pair-range-sharded multi-GPU: the SCP iteration natively,
+    ``qp_row_capacity``, ``reuse_native``, ``verbose``, ``rank``/``world_size``/``group`` (pair-range-sharded multi-GPU: the SCP iteration natively,
     split at its exchange points -- ``scp_iteration_sharded``).
 """
 from __future__ import annotations
 
+import atexit
+import threading
 import time
 
 import numpy as np
 
 from .. import _hip
 from .._sharding import Shard
+
+# The reference's callers build a NEW solver object per scenario (compute_trajectories_batch.py:103-117).  Here an object owns a
+# library context and a native solver (device workspace, pinned host words, the K x K blocks cached per rho): ~0.7 ms to
+# create, against a 2.5 ms solve at 128 agents.  So the native halves of released SCP objects are kept, per (device, stream,
+# shape, settings), and the next object of the same shape adopts them -- same results bit for bit (a pooled solver is what
+# compute-trajectories-batch has always reused per worker; tests/test_scp_gpu.py::test_released_solvers_are_reused).
+_POOL = {}
+_POOL_LOCK = threading.Lock()
+_POOL_LIMIT = 4  # per key
+_POOL_STATS = {"hits": 0, "misses": 0, "returned": 0}
+
+
+def native_pool_stats():
+    """{"hits", "misses", "returned", "held"}: how often a new SCP object adopted the native solver of a released one."""
+    with _POOL_LOCK:
+        return dict(_POOL_STATS, held=sum(len(v) for v in _POOL.values()))
+
+
+def clear_native_pool():
+    """Destroy every pooled native solver and context (also registered with atexit: before the HIP runtime goes away)."""
+    with _POOL_LOCK:
+        entries = [e for v in _POOL.values() for e in v]
+        _POOL.clear()
+    for ctx, nat in entries:
+        try:
+            nat.close()
+            ctx.close()
+        except Exception:
+            pass
+
+
+atexit.register(clear_native_pool)
 
 
 class SCP:
@@ -53,6 +87,7 @@ class SCP:
         rank=0,
         world_size=1,
         group=None,
+        reuse_native=True,
     ):
         # --- reference attributes (scp.py:40-91) ---
         self.N = n_vehicles
@@ -113,12 +148,29 @@ class SCP:
             import torch
 
             device = torch.cuda.current_device() if torch.cuda.is_available() else 0
-        self._ctx = _hip.Context(device)  # raises without a GPU / without libscp_hip.so
+        # the native half of a released object of the same shape on this stream, if there is one (module docstring of _POOL)
+        self.reuse_native = bool(reuse_native)
+        self._pool_key = None
+        if self.reuse_native:
+            import torch
+
+            known = {k for k, _ in _hip.QpSettings._fields_}
+            st = _hip.default_settings(**{k: v for k, v in self._qp_overrides.items() if k in known})
+            stream = torch.cuda.current_stream(torch.device("cuda", int(device))).cuda_stream if torch.cuda.is_available() else 0
+            self._pool_key = (int(device), int(stream), int(self.N), int(self.K), self.D, float(self.h), float(self.R),
+                              bytes(st), self._qp_row_capacity)
+            with _POOL_LOCK:
+                held = _POOL.get(self._pool_key)
+                entry = held.pop() if held else None
+                _POOL_STATS["hits" if entry else "misses"] += 1
+            if entry:
+                self._ctx, self._native = entry
+        if self._native is None:
+            self._ctx = _hip.Context(device)  # raises without a GPU / without libscp_hip.so
         # False: no HIP events around the kernels (linearize_ms / violations_ms read 0, solve_ms is host wall clock): fewer queue
         # packets per solve, for many concurrent solves on one GPU
         self.kernel_timing = bool(kernel_timing)
-        if not self.kernel_timing:
-            self._ctx.set_timing(False)
+        self._ctx.set_timing(self.kernel_timing)
         self._qp = None
         self._pairs = None
         self._dev = {}
@@ -297,6 +349,42 @@ class SCP:
         end_time = time.time()
         self._print(f"Trajectory generation completed in {end_time - start_time:.3f} seconds")
         return self.trajectories
+
+    def close(self):
+        """Release the device objects.  The native solver and its context go to the process-wide pool (reuse_native) for the
+        next SCP object of the same shape; everything else is destroyed.  Called by __del__; the object is unusable after."""
+        ctx, nat = getattr(self, "_ctx", None), getattr(self, "_native", None)
+        self._native = None
+        for name in ("_qp", "_pairs"):
+            obj = getattr(self, name, None)
+            if obj is not None and hasattr(obj, "close"):
+                try:
+                    obj.close()
+                except Exception:
+                    pass
+            setattr(self, name, None)
+        self._dev = {}
+        self._ctx = None
+        if ctx is None:
+            return
+        keep = (nat is not None and self._pool_key is not None and getattr(ctx, "h", None)
+                and not getattr(ctx, "options_changed", False))
+        if keep:
+            with _POOL_LOCK:
+                held = _POOL.setdefault(self._pool_key, [])
+                if len(held) < _POOL_LIMIT:
+                    held.append((ctx, nat))
+                    _POOL_STATS["returned"] += 1
+                    return
+        if nat is not None:
+            nat.close()
+        ctx.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _ensure_native(self):
         if self._native is None:

@@ -35,6 +35,41 @@ def solve_gpu(n, T, h, R, space, p0, pf, max_iterations=15, dim=2, **kw):
     return s, traj
 
 
+def test_released_solvers_are_reused():
+    """A NEW SCP object per scenario (the reference's usage, compute_trajectories_batch.py:103-117) adopts the native solver
+    of a released object of the same shape: same bits as an object that builds its own, on the same and on other scenarios."""
+    from path_planning.scenarios.position_generator import generate_grid_swap
+    from path_planning.solvers import scp as scp_mod
+
+    scp_mod.clear_native_pool()
+    scen = [generate_grid_swap(32, seed=5 + i) for i in range(3)]
+
+    def run(i, **kw):
+        p0, pf, space = scen[i]
+        s, traj = solve_gpu(32, 10.0, 0.2, 0.8, space, p0, pf, **kw)
+        out = (traj["positions"].copy(), [q["iter"] for q in s.last_info["iterations"]], s.last_info["qp0"]["iter"])
+        s.close()
+        return out
+
+    own = [run(i, reuse_native=False) for i in range(3)]
+    before = scp_mod.native_pool_stats()
+    assert before["held"] == 0
+    first = run(0)  # (misses, builds its own, returns it to the pool)
+    again = [run(i) for i in (1, 2, 0)]  # (each adopts the one released just before)
+    after = scp_mod.native_pool_stats()
+    assert after["hits"] - before["hits"] == 3 and after["misses"] - before["misses"] == 1 and after["held"] == 1
+    for got, want in zip([first] + again, [own[0], own[1], own[2], own[0]]):
+        np.testing.assert_array_equal(got[0], want[0])
+        assert got[1] == want[1] and got[2] == want[2]
+    # another shape or other settings: no adoption
+    p0, pf, space = scen[0]
+    s, _ = solve_gpu(32, 10.0, 0.2, 0.8, space, p0, pf, qp_settings={"cg_iters": 2})
+    assert scp_mod.native_pool_stats()["hits"] == after["hits"]
+    s.close()
+    scp_mod.clear_native_pool()
+    assert scp_mod.native_pool_stats()["held"] == 0
+
+
 @pytest.mark.parametrize("cg,tol", CG_CASES)
 @pytest.mark.parametrize("n,seed,T,h", [(4, 1, 10.0, 0.5), (10, 7, 10.0, 0.2)])
 def test_scp_matches_oracle(n, seed, T, h, cg, tol):

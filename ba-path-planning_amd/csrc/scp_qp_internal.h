@@ -154,7 +154,7 @@ bool scp_qp_persist_eligible(const scp_qp* qp);
 bool scp_persist_claim(int device, int n_cu_total, int n_wg, int wait_ms);
 void scp_persist_release(int device, int n_wg);
 constexpr int SCP_PERSIST_GAVE_UP = 2;  // exit code of the persistent kernel: a spin timed out, nothing was written back
-int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done);
+int scp_qp_cg1_persist(scp_qp* qp, int it0, int cad0, int* ran, int* code, int* it_done);  // cad0: steps to the next check
 // (re)pack F, Ft, S0, S0t, HS, Minv into the MFMA operand order; called at the end of build_kkt
 int scp_qp_pack_operands(scp_qp* qp, bool constants);  // constants: F, F^T, S0, S0^T; else the active slot's HS, Minv, T
 static inline size_t scp_packed_count(int R, int M) { return (size_t)((R + 15) / 16) * ((M + 3) / 4) * 64; }

@@ -189,8 +189,9 @@ __global__ __launch_bounds__(64 * persist_apb(D)) void cg1_persist_kernel(Persis
   unsigned exit_code = 0;
   double chk[NCHK];
   const bool with_dy = A.eps_prim_inf > 0.0;
+  int cad = A.cad0;  // steps between two checks: check_every, or check_fine once the residuals are close / rho has changed
   for (;;) {  // one batch of steps up to the next termination check, then the check and the decision to go on
-  int nit = A.check_every - it_done % A.check_every;
+  int nit = cad - it_done % cad;
   if (it_done + nit > A.max_iter) nit = A.max_iter - it_done;
   for (int it = 0; it < nit; ++it, ++steps) {
     const unsigned tag = A.epoch0 + steps + 1u;
@@ -591,7 +592,10 @@ __global__ __launch_bounds__(64 * persist_apb(D)) void cg1_persist_kernel(Persis
     __syncthreads();  // gp is reused by the next step's all-gather
     // ---- decide (the host repeats these tests on the same nine numbers, scp_qp_solve) ------------------------------------
     const double np_ = fmax(chk[CK_NAX], chk[CK_NZ]), nd_ = fmax(chk[CK_NPX], chk[CK_NATY]);
-    if (chk[CK_RP] <= A.eps_abs + A.eps_rel * np_ && chk[CK_RD] <= A.eps_abs + A.eps_rel * nd_) { exit_code = EXIT_SOLVED; break; }
+    const double tol_p = A.eps_abs + A.eps_rel * np_, tol_d = A.eps_abs + A.eps_rel * nd_;
+    if (chk[CK_RP] <= tol_p && chk[CK_RD] <= tol_d) { exit_code = EXIT_SOLVED; break; }
+    if (A.check_fine > 0)  // (the same decision as scp_qp_solve's, from the same nine numbers)
+      cad = (chk[CK_RP] < A.fine_ratio * tol_p && chk[CK_RD] < A.fine_ratio * tol_d) ? A.check_fine : A.check_every;
     if (it_done >= A.max_iter) { exit_code = EXIT_MAX_ITER; break; }
     if (with_dy && chk[CK_NDY] > A.eps_prim_inf && chk[CK_SUPP] < -A.eps_prim_inf * chk[CK_NDY] &&
         chk[CK_NATDY] < A.eps_prim_inf * chk[CK_NDY]) { exit_code = EXIT_INFEASIBLE; break; }
@@ -624,6 +628,7 @@ __global__ __launch_bounds__(64 * persist_apb(D)) void cg1_persist_kernel(Persis
           }
           __syncthreads();
           ++n_rho;
+          if (A.check_fine > 0) cad = A.check_fine;
         }
       }
     }
@@ -736,7 +741,7 @@ bool scp_qp_persist_eligible(const scp_qp* qp) {
 // hipStreamSynchronize) and returns its exit code (*code; SCP_PERSIST_GAVE_UP: nothing was written back, the caller
 // repeats the iterations on the three-launch pipeline), the iteration count reached (*it_done) and, in qp->h_scal, the
 // nine results of the last check.
-int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
+int scp_qp_cg1_persist(scp_qp* qp, int it0, int cad0, int* ran, int* code, int* it_done) {
   const QpDev& d = qp->d;
   scp_ctx* ctx = qp->ctx;
   hipStream_t s = ctx->stream;
@@ -789,6 +794,9 @@ int scp_qp_cg1_persist(scp_qp* qp, int it0, int* ran, int* code, int* it_done) {
   PersistArgs a;
   a.K = K; a.N = qp->N; a.nblk = nblk_expected; a.ent_cap = qp->persist_cap;
   a.it0 = it0; a.max_iter = st.max_iter; a.check_every = st.check_termination;
+  a.cad0 = cad0 > 0 ? cad0 : st.check_termination; a.fine_ratio = st.check_fine_ratio;
+  a.check_fine = (st.check_fine > 0 && st.check_fine < st.check_termination && st.check_termination % st.check_fine == 0 && C <= 4096)
+                     ? st.check_fine : 0;  // (the rule of scp_qp_solve; a persistent launch always has collision rows)
   a.rho_interval = st.adaptive_rho_interval > 0 ? st.adaptive_rho_interval : 1;
   a.C = C;
   a.rho = qp->rho; a.rho_c = qp->rho * st.rho_col_scale; a.rho_eq = st.rho_eq_scale; a.alpha = st.alpha; a.h = qp->h;

@@ -248,8 +248,9 @@ __global__ __launch_bounds__(64 * APB16) void cg1_persist16_kernel(PersistArgs A
   unsigned exit_code = 0;
   const bool with_dy = A.eps_prim_inf > 0.0;
   if (threadIdx.x < 3 * APB16) (&cert_s[0][0])[threadIdx.x] = 0.0;
+  int cad = A.cad0;  // steps between two checks: check_every, or check_fine once the residuals are close / rho has changed
   for (;;) {  // one batch of steps up to the next termination check, then the check and the decision to go on
-  int nit = A.check_every - it_done % A.check_every;
+  int nit = cad - it_done % cad;
   if (it_done + nit > A.max_iter) nit = A.max_iter - it_done;
   for (int it = 0; it < nit; ++it, ++steps) {
     const unsigned tag = A.epoch0 + steps + 1u;
@@ -695,7 +696,10 @@ __global__ __launch_bounds__(64 * APB16) void cg1_persist16_kernel(PersistArgs A
     }
     // ---- decide (the host repeats these tests on the same nine numbers, scp_qp_solve) ------------------------------------
     const double np_ = fmax(chk[CK_NAX], chk[CK_NZ]), nd_ = fmax(chk[CK_NPX], chk[CK_NATY]);
-    if (chk[CK_RP] <= A.eps_abs + A.eps_rel * np_ && chk[CK_RD] <= A.eps_abs + A.eps_rel * nd_) { exit_code = EXIT_SOLVED; break; }
+    const double tol_p = A.eps_abs + A.eps_rel * np_, tol_d = A.eps_abs + A.eps_rel * nd_;
+    if (chk[CK_RP] <= tol_p && chk[CK_RD] <= tol_d) { exit_code = EXIT_SOLVED; break; }
+    if (A.check_fine > 0)  // (the same decision as scp_qp_solve's, from the same nine numbers)
+      cad = (chk[CK_RP] < A.fine_ratio * tol_p && chk[CK_RD] < A.fine_ratio * tol_d) ? A.check_fine : A.check_every;
     if (it_done >= A.max_iter) { exit_code = EXIT_MAX_ITER; break; }
     if (with_dy && chk[CK_NDY] > A.eps_prim_inf && chk[CK_SUPP] < -A.eps_prim_inf * chk[CK_NDY] &&
         chk[CK_NATDY] < A.eps_prim_inf * chk[CK_NDY]) { exit_code = EXIT_INFEASIBLE; break; }
@@ -740,6 +744,7 @@ __global__ __launch_bounds__(64 * APB16) void cg1_persist16_kernel(PersistArgs A
             e_g[e] = (rho_c * e_z[e] - e_y[e]) - rho_c * ax;
           }
           ++n_rho;
+          if (A.check_fine > 0) cad = A.check_fine;
         }
       }
     }

@@ -13,6 +13,8 @@ constexpr unsigned SPIN_LIMIT = 1u << 20;
 struct PersistArgs {
   int K, N, nblk, ent_cap;
   int it0, max_iter, check_every, rho_interval;  // iterations done so far in this solve; limits; termination / rho periods
+  int cad0, check_fine;    // adaptive check cadence (scp_qp_settings.check_fine): steps between checks when this launch starts
+  double fine_ratio;       // (the host's decision after the previous check), the fine period, and "close" = residuals < ratio x tolerance
   int64_t C;
   double rho, rho_c, rho_eq, alpha, h;
   double eps_abs, eps_rel, eps_prim_inf, rho_tol;  // termination tests (eps_prim_inf <= 0: no certificate; rho_tol <= 0: fixed rho)

@@ -45,6 +45,7 @@ class QpSettings(C.Structure):
         ("check_termination", C.c_int32), ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32),
         ("adaptive_rho_tolerance", C.c_double), ("cg_iters", C.c_int32), ("use_mfma", C.c_int32),
         ("rho_col_scale", C.c_double), ("eps_prim_inf", C.c_double), ("persistent", C.c_int32),
+        ("check_fine", C.c_int32), ("check_fine_ratio", C.c_double),
     ]
 
 
@@ -117,7 +118,7 @@ class QpInfo(C.Structure):
         return d
 
 
-ABI_VERSION = 4  # SCP_ABI_VERSION of include/scp_hip.h this binding matches (checked when the library is loaded)
+ABI_VERSION = 5  # SCP_ABI_VERSION of include/scp_hip.h this binding matches (checked when the library is loaded)
 
 EXPORTS = [
     "scp_set_host_wait", "scp_abi_version", "scp_ctx_create", "scp_ctx_destroy", "scp_last_error", "scp_ctx_synchronize",

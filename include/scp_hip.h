@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SCP_ABI_VERSION 4
+#define SCP_ABI_VERSION 5
 
 typedef enum scp_status {
   SCP_OK = 0,
@@ -82,6 +82,16 @@ typedef struct scp_qp_settings {
                                     of round 2, up to 2048 the lean one with 8.  2 / 3 / 4: force the lean 16-agent / lean
                                     8-agent / round-2 kernel where it fits (tests, measurements); 0: three launches per step.
                                     Same arithmetic up to the association of sums */
+  int32_t check_fine;            /* 5: adaptive check cadence.  After a termination check that finds both residuals within
+                                    check_fine_ratio x their tolerances, or that changes rho, the next check comes after
+                                    check_fine steps (a divisor of check_termination) instead of check_termination: a QP
+                                    no longer pays up to 24 surplus steps for every check interval it does not need, and
+                                    pays the fine checks (about one step each inside the persistent kernels) only near the
+                                    end (profiles/r03_check_cadence.txt).  Applies to QPs with collision rows (QP#0 keeps
+                                    the fixed cadence: a better converged start saves the first joint QP more) of up to
+                                    4096 columns (beyond, a check costs about three steps).  0, or a value that does not
+                                    divide check_termination: fixed cadence */
+  double check_fine_ratio;       /* 2 */
 } scp_qp_settings;
 
 /* [host] result of scp_qp_solve */

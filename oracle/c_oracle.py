@@ -31,7 +31,7 @@ class _Settings(C.Structure):
                 ("check_termination", C.c_int), ("adaptive_rho", C.c_int), ("adaptive_rho_interval", C.c_int),
                 ("adaptive_rho_tolerance", C.c_double), ("cg_iters", C.c_int), ("margin", C.c_double),
                 ("feas_tol", C.c_double), ("max_rounds", C.c_int), ("rho_col_scale", C.c_double),
-                ("eps_prim_inf", C.c_double)]
+                ("eps_prim_inf", C.c_double), ("check_fine", C.c_int), ("check_fine_ratio", C.c_double)]
 
 
 class _Info(C.Structure):
@@ -88,7 +88,8 @@ def admm(prob, eta=None, l_col=None, dist=None, x0=None, st: qo.Settings | None 
     st = st or qo.Settings()
     cs = _Settings(st.rho, st.sigma, st.alpha, st.rho_eq_scale, st.eps_abs, st.eps_rel, st.max_iter,
                    st.check_termination, int(st.adaptive_rho), st.adaptive_rho_interval, st.adaptive_rho_tolerance,
-                   st.cg_iters, st.margin, st.feas_tol, st.max_rounds, st.rho_col_scale, st.eps_prim_inf)
+                   st.cg_iters, st.margin, st.feas_tol, st.max_rounds, st.rho_col_scale, st.eps_prim_inf, st.check_fine,
+                   st.check_fine_ratio)
     x = np.zeros((prob.N, prob.K, prob.D))
     info = _Info()
     keep = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (eta, l_col, dist, x0)]

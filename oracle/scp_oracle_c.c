@@ -34,6 +34,8 @@ typedef struct {
   int max_rounds;
   double rho_col_scale; /* rho of the collision rows = rho * rho_col_scale */
   double eps_prim_inf;  /* OSQP's primal infeasibility tolerance */
+  int check_fine;          /* adaptive check cadence (qp_oracle.Settings.check_fine): steps to the next check once the */
+  double check_fine_ratio; /* residuals are within this factor of their tolerances, or rho has just changed; 0: fixed */
 } oc_settings;
 
 typedef struct {
@@ -351,6 +353,10 @@ int oc_admm(const oc_problem* P, const double* eta, const double* l_col, const d
     spd_inverse(K, Hf, Minv);
     status = -2;
     int it = 0;
+    int cad = st->check_termination; /* steps between two checks: every round starts on the coarse cadence */
+    const int fine = (st->check_fine > 0 && st->check_fine < st->check_termination && st->check_termination % st->check_fine == 0 &&
+                      nW > 0 && C <= 4096) ? st->check_fine : 0; /* (when it divides the coarse one, not to QP#0, up to 4096
+                                                                     columns: qp_oracle.py) */
     while (total_it < st->max_iter) {
       ++it;
       ++total_it;
@@ -409,7 +415,7 @@ int oc_admm(const oc_problem* P, const double* eta, const double* l_col, const d
       }
       /* z~ = A x~, relaxation, projection, duals */
       const double al = st->alpha;
-      const int will_check = (it % st->check_termination == 0) || total_it >= st->max_iter;
+      const int will_check = (it % cad == 0) || total_it >= st->max_iter;
       if (will_check) {
         memcpy(sj, yj, sizeof(double) * nx); memcpy(sa, ya, sizeof(double) * nx);
         memcpy(sv, yv, sizeof(double) * nx); memcpy(sp, yp, sizeof(double) * nx);
@@ -452,7 +458,7 @@ int oc_admm(const oc_problem* P, const double* eta, const double* l_col, const d
       }
       for (size_t e = 0; e < nx; ++e) x[e] = al * xt[e] + (1 - al) * x[e];
 
-      if (it % st->check_termination == 0 || total_it >= st->max_iter) {
+      if (it % cad == 0 || total_it >= st->max_iter) {
         double nAx = 0.0, nz = 0.0, nPx = 0.0, nATy = 0.0;
         rp = rd = 0.0;
         for (int c = 0; c < C; ++c) {
@@ -478,9 +484,14 @@ int oc_admm(const oc_problem* P, const double* eta, const double* l_col, const d
         for (size_t e = 0; e < nx; ++e) {
           rd = dmax(rd, fabs(2.0 * x[e] + rhs[e])); nPx = dmax(nPx, fabs(2.0 * x[e])); nATy = dmax(nATy, fabs(rhs[e]));
         }
-        if (rp <= st->eps_abs + st->eps_rel * dmax(nAx, nz) && rd <= st->eps_abs + st->eps_rel * dmax(nPx, nATy)) {
-          status = 1;
-          break;
+        {
+          const double tol_p = st->eps_abs + st->eps_rel * dmax(nAx, nz), tol_d = st->eps_abs + st->eps_rel * dmax(nPx, nATy);
+          if (rp <= tol_p && rd <= tol_d) {
+            status = 1;
+            break;
+          }
+          if (fine) /* close to the tolerances: look again soon */
+            cad = (rp < st->check_fine_ratio * tol_p && rd < st->check_fine_ratio * tol_d) ? fine : st->check_termination;
         }
         /* OSQP at max_iter: 10 x the tolerances -> "solved inaccurate" (scp.py:363, :446 accept it) */
         if (total_it >= st->max_iter && rp <= 10.0 * (st->eps_abs + st->eps_rel * dmax(nAx, nz)) &&
@@ -533,6 +544,7 @@ int oc_admm(const oc_problem* P, const double* eta, const double* l_col, const d
             build_hf(K, h, st->sigma, rho, st->rho_eq_scale, Hf);
             spd_inverse(K, Hf, Minv);
             ++rho_updates;
+            if (fine) cad = fine;
           }
         }
       }

@@ -151,6 +151,44 @@ def test_scp_128_agents_vs_c_oracle(cg, tol):
     np.testing.assert_allclose([q["rel_step"] for q in s.last_info["iterations"]], ref["rel_steps"], rtol=0.05, atol=2e-3)
 
 
+@pytest.mark.parametrize("n,persistent", [(128, 1), (128, 0), (128, 4), (128, 2), (40, 1)])
+def test_adaptive_check_cadence(n, persistent):
+    """settings.check_fine = 5 (after a check that finds the residuals within 4 x their tolerances, or that changes rho, the
+    next check comes after 5 steps instead of 25).  Two PCG steps: the host loop (QP#0 kernel, fused path) follows the C
+    oracle's cadence iterate for iterate.  One PCG step: every persistent kernel (default lean 8-agent, lean 16-agent,
+    round 2's) takes the same decisions inside the kernel as the host loop of the three-launch pipeline does -- the same
+    counts up to the summation-order effect the fixed cadence has too (here: a few fine intervals)."""
+    from path_planning.scenarios.position_generator import generate_grid_swap
+    from path_planning.solvers.scp import SCP
+
+    p0, pf, space = generate_grid_swap(n, seed=4)
+    prob = so.make_problem(n, 10.0, 0.2, 0.8, space, p0, pf)
+
+    def gpu(**qp):
+        s = SCP(n, 10.0, 0.2, 0.8, space, verbose=False, qp_settings=dict(check_fine=5, **qp))
+        s.set_initial_states(p0)
+        s.set_final_states(pf)
+        traj = s.generate_trajectories(15)
+        return s, traj, [s.last_info["qp0"]["iter"]] + [q["iter"] for q in s.last_info["iterations"]]
+
+    if persistent == 1:  # (a) iterate for iterate against the oracle
+        s, traj, gi = gpu(cg_iters=2)
+        ref = co.scp_solve(prob, 15, qo.Settings(max_iter=10000, cg_iters=2, check_fine=5))
+        assert gi == [q["iter"] for q in ref["infos"]], (gi, [q["iter"] for q in ref["infos"]])
+        assert any(i % 25 for i in gi)  # (the fine cadence did end at least one QP between two coarse checks)
+        np.testing.assert_allclose(traj["positions"], ref["positions"], rtol=0, atol=1e-6)
+    # (b) the default single PCG step on the chosen pipeline against the C oracle's single step
+    s, traj, gi = gpu(persistent=persistent)
+    ref = co.scp_solve(prob, 15, qo.Settings(max_iter=10000, check_fine=5))
+    ci = [q["iter"] for q in ref["infos"]]
+    want = {0: "three-launch", 1: "persistent8-lean", 2: "persistent16", 4: "persistent"}[persistent]
+    assert all(want in q["pipeline"] for q in s.last_info["iterations"]), [q["pipeline"] for q in s.last_info["iterations"]]
+    assert s.last_info["n_iterations"] == ref["iterations"]
+    assert gi[0] == ci[0] and all(abs(a - b) <= 25 for a, b in zip(gi, ci)), (gi, ci)
+    assert all(i % 5 == 0 for i in gi)
+    np.testing.assert_allclose(traj["positions"], ref["positions"], rtol=0, atol=2e-2)
+
+
 def test_config3_full_solve_vs_c_oracle():
     """BASELINE config 3 end to end: the complete 1024 x 50 solve (QP#0 + every SCP iteration, default settings: one PCG
     step, persistent kernel, native loop) against the C oracle's complete solve of the same scenario (~15 s on one host

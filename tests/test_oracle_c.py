@@ -49,8 +49,10 @@ def test_c_admm_vs_numpy(n, seed, T, h):
     eta, l_col, dist = so.linearize_pairs(prob, pos)
     # two PCG steps: iterate for iterate; the default single step is not contractive during the transient and can amplify the
     # 1e-16 between two summation orders (numpy einsum vs C loops) by up to 1e7 on small, nearly degenerate QPs before both
-    # converge to the same point: the same counts, waypoints to 1e-6
-    for cg, tol in ((2, 1e-9), (1, 1e-6)):
+    # converge to the same point: the same counts, waypoints to the solver's tolerance class (the adaptive
+    # check cadence stops a QP up to 20 steps earlier than the fixed one did, i.e. earlier in that decay: 3e-4 observed on the
+    # 4-agent case where the fixed cadence left 1e-7)
+    for cg, tol in ((2, 1e-9), (1, 1e-3)):
         st = qo.Settings(max_iter=10000, cg_iters=cg)
         x1, _, i1 = qo.admm_structured(prob, eta, l_col, dist, x0=x0, st=st)
         xc, ic = co.admm(prob, eta, l_col, dist, x0, st)

@@ -380,7 +380,9 @@ def test_scp_sweep_vs_oracle(kind, n, seed, cg):
         if cg > 1:
             assert a["iter"] == b["iter"] and a["working_rows"] == b["working_rows"], (a, b)
         else:
-            assert abs(a["iter"] - b["iter"]) <= 50 and abs(a["working_rows"] - b["working_rows"]) <= 2, (a, b)
+            # (three coarse check intervals: one of the seven cases lands 60 steps apart since the adaptive check cadence
+            # moved where its two constraint-generation rounds end -- 165 against 225, the same final rows and rel. step)
+            assert abs(a["iter"] - b["iter"]) <= 75 and abs(a["working_rows"] - b["working_rows"]) <= 2, (a, b)
     # cg = 1: eps_abs + eps_rel * max|Ax| = 1e-3 * (1 + ~20 m), the primal residual either solver may stop at
     np.testing.assert_allclose(traj["positions"], out["positions"], rtol=0, atol=2e-2 if cg == 1 else 1e-6)
     np.testing.assert_allclose([i["rel_step"] for i in s.last_info["iterations"]], out["rel_steps"], rtol=0.05, atol=2e-3)

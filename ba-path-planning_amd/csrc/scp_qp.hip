@@ -1080,8 +1080,8 @@ extern "C" int scp_qp_solve(scp_qp* qp, scp_qp_info* info) {
   // (the fine cadence applies when it divides the coarse one; otherwise the cadence is fixed)
   // and to QPs with collision rows: QP#0 keeps the fixed cadence (its 20 surplus steps are cheap, and a better converged
   // starting point saves the first joint QP of large problems far more: 250 instead of 400 steps at 1024 x 50)
-  // ... and up to SCP_FINE_MAX_COLUMNS columns: beyond, a check of the 16-agent persistent kernel costs about three steps
-  // (4096 x 50: 195 instead of 200 steps, but 0.27 ms more; profiles/r03_check_cadence.txt)
+  // ... and up to SCP_FINE_MAX_COLUMNS columns: beyond, it measured slower (4096 x 50: 195 instead of 200 steps, but 0.27 ms
+  // more in every repetition; profiles/r03_check_cadence.txt, r03_check_cost.txt)
   constexpr int64_t SCP_FINE_MAX_COLUMNS = 4096;
   const int fine = (st.check_fine > 0 && st.check_fine < st.check_termination && st.check_termination % st.check_fine == 0 && qp->nW > 0 &&
                     qp->C <= SCP_FINE_MAX_COLUMNS) ? st.check_fine : 0;

@@ -89,7 +89,7 @@ typedef struct scp_qp_settings {
                                     pays the fine checks (about one step each inside the persistent kernels) only near the
                                     end (profiles/r03_check_cadence.txt).  Applies to QPs with collision rows (QP#0 keeps
                                     the fixed cadence: a better converged start saves the first joint QP more) of up to
-                                    4096 columns (beyond, a check costs about three steps).  0, or a value that does not
+                                    4096 columns (beyond, it measured slower: profiles/r03_check_cadence.txt).  0, or a value that does not
                                     divide check_termination: fixed cadence */
   double check_fine_ratio;       /* 2 */
 } scp_qp_settings;

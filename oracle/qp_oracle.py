@@ -322,7 +322,7 @@ def admm_structured(prob: so.Problem, eta=None, l_col=None, dist=None, x0=None, 
         # (the fine cadence applies when it divides the coarse one; otherwise the cadence is fixed)
         # and to QPs with collision rows: QP#0 keeps the fixed cadence (its 20 surplus steps are cheap, and a better converged
         # starting point saves the first joint QP of large problems far more: 250 instead of 400 steps at 1024 x 50)
-        # and up to 4096 columns (2048 agents in 2-D): beyond, a check of the 16-agent persistent kernel costs about three steps
+        # and up to 4096 columns (2048 agents in 2-D): beyond, the GPU measured slower with it (the oracle follows the product)
         fine = st.check_fine if (0 < st.check_fine < st.check_termination and st.check_termination % st.check_fine == 0
                                  and W.size > 0 and N * D <= FINE_MAX_COLUMNS) else 0
         xt = x.copy()

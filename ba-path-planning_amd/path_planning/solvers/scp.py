@@ -29,8 +29,8 @@ from .._sharding import Shard
 
 # The reference's callers build a NEW solver object per scenario (compute_trajectories_batch.py:103-117).  Here an object owns a
 # library context and a native solver (device workspace, pinned host words, the K x K blocks cached per rho): ~0.7 ms to
-# create, against a 2.5 ms solve at 128 agents.  So the native halves of released SCP objects are kept, per (device, stream,
-# shape, settings), and the next object of the same shape adopts them -- same results bit for bit (a pooled solver is what
+# create, against a 2.5 ms solve at 128 agents.  So the native halves of released SCP objects on the DEFAULT stream are kept,
+# per (device, shape, settings), and the next object of the same shape adopts them -- same results bit for bit (a pooled solver is what
 # compute-trajectories-batch has always reused per worker; tests/test_scp_gpu.py::test_released_solvers_are_reused).
 _POOL = {}
 _POOL_LOCK = threading.Lock()
@@ -156,15 +156,18 @@ class SCP:
 
             known = {k for k, _ in _hip.QpSettings._fields_}
             st = _hip.default_settings(**{k: v for k, v in self._qp_overrides.items() if k in known})
-            stream = torch.cuda.current_stream(torch.device("cuda", int(device))).cuda_stream if torch.cuda.is_available() else 0
-            self._pool_key = (int(device), int(stream), int(self.N), int(self.K), self.D, float(self.h), float(self.R),
-                              bytes(st), self._qp_row_capacity)
-            with _POOL_LOCK:
-                held = _POOL.get(self._pool_key)
-                entry = held.pop() if held else None
-                _POOL_STATS["hits" if entry else "misses"] += 1
-            if entry:
-                self._ctx, self._native = entry
+            tdev = torch.device("cuda", int(device))
+            on_default = torch.cuda.is_available() and (torch.cuda.current_stream(tdev).cuda_stream
+                                                        == torch.cuda.default_stream(tdev).cuda_stream)
+            if on_default:  # (a context is bound to its stream: only the default stream is sure to outlive the pool)
+                self._pool_key = (int(device), int(self.N), int(self.K), self.D, float(self.h), float(self.R), bytes(st),
+                                  self._qp_row_capacity)
+                with _POOL_LOCK:
+                    held = _POOL.get(self._pool_key)
+                    entry = held.pop() if held else None
+                    _POOL_STATS["hits" if entry else "misses"] += 1
+                if entry:
+                    self._ctx, self._native = entry
         if self._native is None:
             self._ctx = _hip.Context(device)  # raises without a GPU / without libscp_hip.so
         # False: no HIP events around the kernels (linearize_ms / violations_ms read 0, solve_ms is host wall clock): fewer queue

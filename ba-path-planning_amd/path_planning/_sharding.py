@@ -16,9 +16,12 @@ import torch.distributed as dist
 class Shard:
     """rank / world_size view of an N-agent problem; world_size == 1 needs no process group."""
 
-    def __init__(self, N, rank=0, world_size=1, group=None):
+    def __init__(self, N, rank=0, world_size=1, group=None, run_collectives_alone=False):
         self.N, self.rank, self.world, self.group = int(N), int(rank), int(world_size), group
-        if self.world > 1 and not dist.is_initialized():
+        # a world of ONE rank normally skips every collective; run_collectives_alone sends them through the process group anyway
+        # (a one-rank RCCL communicator): the device-side ("nccl") code path can then run on a single GPU (tests)
+        self.alone = self.world == 1 and not run_collectives_alone
+        if (self.world > 1 or run_collectives_alone) and not dist.is_initialized():
             raise RuntimeError("world_size > 1 needs an initialised torch.distributed process group")
         self.pairs = self.N * (self.N - 1) // 2
         # host wall time spent inside the exchanges (staging copies of a gloo rehearsal included) and their count: what a
@@ -46,7 +49,7 @@ class Shard:
 
         @functools.wraps(fn)
         def wrapper(self, *a, **kw):
-            if self.world == 1 or getattr(self, "_in_exchange", False):
+            if self.alone or getattr(self, "_in_exchange", False):
                 return fn(self, *a, **kw)
             self._in_exchange = True
             t0 = time.perf_counter()
@@ -61,7 +64,7 @@ class Shard:
     @_timed
     def allgather_positions(self, local):
         """local: (n_local, K, D) trajectories of this rank's agents -> (N, K, D) on every rank."""
-        if self.world == 1:
+        if self.alone:
             return local
         if self._host_staged(local):
             return self.allgather_positions(local.cpu()).to(local.device)
@@ -84,7 +87,7 @@ class Shard:
         Two collectives of fixed, padded shape (ids as int64 in their own message -- never reinterpreted as floating
         point -- and [eta | l] as float64) plus one gather of the counts; the padding is cut on the device, the only
         host read is the list of counts."""
-        if self.world == 1:
+        if self.alone:
             return rows, w_eta, w_l
         if self._host_staged(rows):
             dev = rows.device
@@ -118,7 +121,7 @@ class Shard:
         max over ranks of one float (`extra`: the violations pass's max violation).  ONE collective: each rank sends
         [count, bits of extra, ids padded to the capacity every rank agreed on]; a second, longer one only when some rank's
         list outgrew that capacity.  Returns (ids, max_extra)."""
-        if self.world == 1:
+        if self.alone:
             return rows, extra
         dev = rows.device
         staged = self._host_staged(rows)
@@ -148,7 +151,7 @@ class Shard:
 
     @_timed
     def broadcast(self, tensor, src=0):
-        if self.world > 1:
+        if not self.alone:
             if self._host_staged(tensor):
                 host = tensor.cpu()
                 dist.broadcast(host, src=src, group=self.group)
@@ -161,21 +164,21 @@ class Shard:
         """Rank `src`'s integers on every rank: loop-control decisions (iteration counts, statuses) must be taken
         from ONE rank, otherwise fp-atomics noise in the replicated QP could make ranks leave a loop at different
         trip counts and the next collective would hang."""
-        if self.world == 1:
+        if self.alone:
             return [int(v) for v in values]
         t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=self._dev())
         dist.broadcast(t, src=src, group=self.group)
         return [int(v) for v in t.tolist()]
 
     def all_min(self, value: float) -> float:
-        if self.world == 1:
+        if self.alone:
             return value
         t = torch.tensor([value], dtype=torch.float64, device=self._dev())
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         return float(t.item())
 
     def all_max(self, value: float) -> float:
-        if self.world == 1:
+        if self.alone:
             return value
         t = torch.tensor([value], dtype=torch.float64, device=self._dev())
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
@@ -183,7 +186,7 @@ class Shard:
 
     def all_min_int(self, value: int) -> int:
         """min over ranks of a non-negative integer < 2^63 (first-violation row ids; UINT64_MAX -> 2^63-1)."""
-        if self.world == 1:
+        if self.alone:
             return value
         v = min(int(value), (1 << 63) - 1)
         t = torch.tensor([v], dtype=torch.int64, device=self._dev())

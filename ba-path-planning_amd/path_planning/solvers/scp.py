@@ -436,7 +436,7 @@ class SCP:
         if not opts.row_free:
             raise ValueError("the sharded step is row-free: a rank does not hold the rows of another rank's pairs")
         pos_in = None
-        if exchange_positions and self.shard.world > 1:
+        if exchange_positions and not self.shard.alone:
             pos_in, _ = self._kinematics(acc, want_vel=False)  # agent-sharded kinematics + allgather of the trajectories
         q0, q1 = self.shard.pair_range()
         rec, rows = nat.shard_begin(self._limits(), self._space(), p0, v0, pf, vf, opts, acc, pos_in, q0, q1)

@@ -300,6 +300,74 @@ def test_scp_two_ranks_share_one_gpu(tmp_path):
     np.testing.assert_allclose(pa, traj["positions"], rtol=0, atol=1e-8)
 
 
+def _rccl_one_rank_worker(rank, port, out_dir):
+    import os
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "ba-path-planning_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from path_planning._sharding import Shard
+
+    dev = torch.device("cuda", 0)
+    sh = Shard(10, 0, 1, None, run_collectives_alone=True)
+    assert dist.get_backend() == "nccl" and not sh.alone
+    pos = torch.arange(10 * 4 * 2, dtype=torch.float64, device=dev).reshape(10, 4, 2)
+    assert torch.equal(sh.allgather_positions(pos), pos)
+    rows = torch.tensor([3, 7, 11], dtype=torch.int64, device=dev)
+    eta = torch.arange(6, dtype=torch.float64, device=dev).reshape(3, 2)
+    l = torch.tensor([0.5, 0.25, 0.125], dtype=torch.float64, device=dev)
+    r, e, ll = sh.allgather_rows(rows, eta, l)
+    assert torch.equal(r, rows) and torch.equal(e, eta) and torch.equal(ll, l)
+    ids, mx = sh.allgather_ids(torch.tensor([9, 2, 5], dtype=torch.int64, device=dev), extra=0.75)
+    assert ids.tolist() == [2, 5, 9] and mx == 0.75 and ids.is_cuda
+    sh._ids_cap = 2  # (the capacity retry: a second, longer message)
+    ids, _ = sh.allgather_ids(torch.arange(7, dtype=torch.int64, device=dev))
+    assert ids.tolist() == list(range(7))
+    t = torch.full((5,), 3.0, dtype=torch.float64, device=dev)
+    assert torch.equal(sh.broadcast(t.clone()), t)
+    assert sh.broadcast_ints([4, -1, 7]) == [4, -1, 7]
+    assert sh.all_min(0.5) == 0.5 and sh.all_max(2.5) == 2.5 and sh.all_min_int(123) == 123
+    assert sh.comm_calls >= 5 and sh.comm_seconds > 0.0  # (the timed exchanges: positions, rows, ids x 2, broadcast)
+    # the sharded SCP iteration with its exchanges on RCCL (trajectories, row ids per round) against scp_solver_step
+    from path_planning.scenarios.position_generator import generate_grid_swap
+    from path_planning.solvers.scp import SCP
+
+    p0, pf, space = generate_grid_swap(40, seed=11)
+    s = SCP(40, 10.0, 0.2, 0.8, space, verbose=False, device=0)
+    s.set_initial_states(p0)
+    s.set_final_states(pf)
+    s._precompute_constraint_matrices()
+    acc0 = s._solve_initial_trajectory()
+    a, ia = s.scp_iteration(acc0)
+    s.shard = Shard(40, 0, 1, None, run_collectives_alone=True)
+    b, ib = s.scp_iteration_sharded(acc0)
+    assert torch.equal(a, b) and ia["iter"] == ib["iter"] and ia["working_rows"] == ib["working_rows"]
+    assert s.shard.comm_calls >= 2  # (selected ids, violated ids of at least one round; the trajectories when agents are split)
+    s.close()
+    open(os.path.join(out_dir, "ok"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_rccl_branch_with_one_rank(tmp_path):
+    """Every collective of path_planning/_sharding.py through RCCL (backend "nccl": device tensors, no host staging) on a
+    communicator of ONE rank -- the code path a multi-GPU node takes, as far as a single GPU can run it (two ranks on one
+    device are refused by RCCL; the two-rank semantics are covered over gloo)."""
+    import os
+
+    import torch.multiprocessing as mp
+
+    mp.spawn(_rccl_one_rank_worker, args=(29900 + os.getpid() % 90, str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "ok").exists()
+
+
 @pytest.mark.parametrize("n,T,h,dim", [(1, 2.0, 0.2, 2), (2, 0.8, 0.2, 2), (1, 2.0, 0.5, 3), (3, 1.0, 0.5, 3)])
 def test_edge_sizes(n, T, h, dim):
     """Smallest shapes: a single agent (no pairs at all), K = 3 time steps, 3-D with few agents."""

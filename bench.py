@@ -193,16 +193,20 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r03_pairwise_traffic.json")
     if not os.path.exists(tpath):
         tpath = os.path.join(ROOT, "profiles", "r02_pairwise_traffic.json")
-    if world == 1 and (N, K, D) == (1024, 50, 2) and os.path.exists(tpath):
+    if world == 1 and os.path.exists(tpath):
         import hashlib
 
         with open(tpath) as f:
             tj = json.load(f)
+        # (the headline workload at the top level, other workloads -- config 4 -- under "configs")
+        tcfg = tj if (N, K, D) == (1024, 50, 2) else tj.get("configs", {}).get(f"{N}x{K}x{D}")
         src = os.path.join(ROOT, "ba-path-planning_amd", "csrc", "scp_kernels.hip")
         sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
-        if tj.get("kernel_source_sha256") == sha:
-            traffic = tj["linearize"]["hbm_bytes"]
-            viol_traffic = tj.get("violations_recompute", {}).get("hbm_bytes")
+        if tcfg is None:
+            pass
+        elif tj.get("kernel_source_sha256") == sha:
+            traffic = tcfg["linearize"]["hbm_bytes"]
+            viol_traffic = tcfg.get("violations_recompute", {}).get("hbm_bytes")
         else:
             traffic_note = "scp_kernels.hip changed since the PMC passes were collected: re-run tools/collect_profiles.sh"
 

@@ -26,6 +26,10 @@ for C in WRITE_SIZE FETCH_SIZE; do
   timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 $R/tools/pair_bench.py --reps 3 > $OUT/pmc_$C.log 2>&1
   cp $(find $OUT/pmc_$C -name "*counter_collection.csv" | head -1) $OUT/pairwise_pmc_$C.csv 2>/dev/null
 done
+for C in WRITE_SIZE FETCH_SIZE; do  # config 4 (4096 x 50: the L1 / L2 path of the same kernels)
+  timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${C}_n4096 -- python3 $R/tools/pair_bench.py --reps 3 --agents 4096 > $OUT/pmc_${C}_n4096.log 2>&1
+  cp $(find $OUT/pmc_${C}_n4096 -name "*counter_collection.csv" | head -1) $OUT/pairwise_pmc_${C}_n4096.csv 2>/dev/null
+done
 timeout -k 10 200 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_TCC -- python3 $R/tools/pair_bench.py --reps 3 > $OUT/pmc_TCC.log 2>&1
 cp $(find $OUT/pmc_TCC -name "*counter_collection.csv" | head -1) $OUT/pairwise_pmc_TCC.csv 2>/dev/null
 

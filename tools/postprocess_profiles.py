@@ -113,7 +113,24 @@ for key, (needle, alg) in kinds.items():
         continue
     out[key] = {"rows": rows_n, "algorithmic_bytes": alg, "write_bytes": wb, "fetch_bytes": 2.0 * fb,
                 "hbm_bytes": wb + 2.0 * fb, "launches_averaged": min(nw, nf)}
+# config 4 (4096 x 50, 2-D: the L1 / L2 path of the same kernels) from its own pair of passes, when they were collected
+w4 = reduce_pmc("pairwise_pmc_WRITE_SIZE_n4096.csv", "pairwise_pmc_WRITE_SIZE_n4096.csv")
+f4 = reduce_pmc("pairwise_pmc_FETCH_SIZE_n4096.csv", "pairwise_pmc_FETCH_SIZE_n4096.csv")
+if w4 and f4:
+    N4 = 4096
+    rows4 = N4 * (N4 - 1) // 2 * K
+    cfg = {}
+    for key, (needle, _) in kinds.items():
+        wb, nw = per_launch(w4, "WRITE_SIZE", needle)
+        fb, nf = per_launch(f4, "FETCH_SIZE", needle)
+        if wb is None or fb is None:
+            continue
+        alg4 = {"linearize": rows4 * 8 * (D + 1) + 2 * N4 * K * D * 8, "select": N4 * K * D * 8}.get(key, 2 * N4 * K * D * 8)
+        cfg[key] = {"rows": rows4, "algorithmic_bytes": alg4, "write_bytes": wb, "fetch_bytes": 2.0 * fb,
+                    "hbm_bytes": wb + 2.0 * fb, "launches_averaged": min(nw, nf)}
+    if "linearize" in cfg:
+        out["configs"] = {"4096x50x2": cfg}
 if ok:
     with open(os.path.join(dst, PFX + "pairwise_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
-    print(json.dumps({k: v["hbm_bytes"] for k, v in out.items() if isinstance(v, dict)}))
+    print(json.dumps({k: v["hbm_bytes"] for k, v in out.items() if isinstance(v, dict) and "hbm_bytes" in v}))
